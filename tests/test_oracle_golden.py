@@ -1,0 +1,176 @@
+"""The CPU oracle (`oracle/sdrm_oracle.py`) against the golden vectors produced by
+the reference itself (`tests/golden/make_golden.py`).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sdrm_oracle as orc
+from sdrm_amd import synth
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).sum()) / max(np.sqrt((b ** 2).sum()), 1e-30))
+
+
+def rel_max(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def split_flat(flat, dims):
+    L, W, T, H = (int(v) for v in dims)
+    return synth.unflatten_params(flat, L, W, T, H)
+
+
+@pytest.mark.parametrize("T", [3, 8, 78, 83, 93, 198])
+def test_schedule(golden, T):
+    g = golden("schedule")
+    b, a, ab = orc.schedule(T)
+    np.testing.assert_array_equal(b.numpy(), g[f"beta_{T}"])
+    np.testing.assert_array_equal(a.numpy(), g[f"alpha_{T}"])
+    np.testing.assert_allclose(ab.numpy(), g[f"alphabar_{T}"], rtol=1e-6, atol=0)
+    assert ab[0] == 1
+
+
+def test_schedule_check_values():
+    # SURVEY.md App. A.1 [measured on the reference]
+    b, a, ab = orc.schedule(83)
+    assert abs(float(ab[1]) - 0.99956030) < 2e-7
+    assert abs(float(ab[83]) - 0.42744946) < 2e-6
+
+
+@pytest.mark.parametrize("T", [3, 7, 8, 78, 83, 93, 198])
+def test_timestep_table(golden, T):
+    g = golden("timestep_embedding")
+    np.testing.assert_allclose(orc.timestep_table(T).numpy(), g[f"temb_{T}"], rtol=0, atol=1e-6)
+
+
+def test_forward(golden):
+    g = golden("forward")
+    for ci in range(int(g["n_cases"])):
+        L, W, T, H = (int(v) for v in g[f"c{ci}_dims"])
+        o = orc.Oracle(L, W, T, H, split_flat(g[f"c{ci}_flat"], (L, W, T, H)))
+        for B in (1, 5):
+            k = f"c{ci}_B{B}"
+            y = o.forward(torch.from_numpy(g[k + "_x"]), torch.from_numpy(g[k + "_t"]),
+                          torch.from_numpy(g[k + "_mask"].astype(np.float32)))
+            assert rel_max(y.numpy(), g[k + "_y"]) < 2e-6, (ci, B)
+
+
+def test_elementwise(golden):
+    g = golden("elementwise")
+    T = int(g["T"])
+    beta, alpha, ab = orc.schedule(T)
+    x, noise, t = (torch.from_numpy(g[k]) for k in ("x", "noise", "t"))
+    np.testing.assert_allclose(orc.q_sample(x, t, noise, ab).numpy(), g["perturbed"], rtol=1e-6, atol=1e-7)
+    eps, z = torch.from_numpy(g["eps"]), torch.from_numpy(g["z"])
+    for i in (T, 5, 2, 1):
+        got = orc.reverse_update(x, eps, z, i, beta, alpha, ab)
+        np.testing.assert_allclose(got.numpy(), g[f"rev_int_{i}"], rtol=2e-6, atol=1e-6)
+    got = orc.reverse_update(x, eps, torch.zeros_like(x), 1, beta, alpha, ab)
+    np.testing.assert_allclose(got.numpy(), g["rev_int_1_nonoise"], rtol=2e-6, atol=1e-6)
+    got = orc.reverse_update(x[:1], eps[:1], z[:1], torch.tensor([4]), beta, alpha, ab)
+    np.testing.assert_allclose(got.numpy(), g["rev_tensor_4"], rtol=2e-6, atol=1e-6)
+
+
+def test_train_runs(golden):
+    """Whole reference `train_SDRM()` runs replayed step by step: P/S/Q, loss,
+    every gradient (shared-layer accumulation), post-Adam parameters across the
+    epoch boundary, final Adam moments."""
+    g = golden("train")
+    for ci in range(int(g["n_cases"])):
+        pf = f"c{ci}_"
+        L, W, T, H = (int(v) for v in g[pf + "dims"])
+        lr0, nd, epochs, nb = g[pf + "hyper"]
+        epochs, nb = int(epochs), int(nb)
+        names = synth.param_names(H)
+        o = orc.Oracle(L, W, T, H, split_flat(g[pf + "init_flat"], (L, W, T, H)))
+        shapes = synth.param_shapes(L, W, T, H)
+        for s in range(epochs * nb):
+            lr = o.epoch_lr(lr0, s // nb, epochs)
+            eps = torch.from_numpy(g[pf + f"s{s}_raw_noise"]) * float(nd)
+            loss, grads, (P, S, Q), xp = o.loss_and_grads(g[pf + f"s{s}_x0"], eps, g[pf + f"s{s}_t"],
+                                                          list(g[pf + f"s{s}_masks"]))
+            if s == 0:
+                assert abs(float(loss) - float(g[pf + "s0_loss"])) <= 2e-6 * abs(float(g[pf + "s0_loss"]))
+                np.testing.assert_allclose(xp.numpy(), g[pf + "s0_xpert"], rtol=1e-6, atol=1e-7)
+            for tag, arr in (("P", P), ("S", S), ("Q", Q)):
+                assert rel_max(arr.numpy(), g[pf + f"s{s}_{tag}"]) < 5e-6, (ci, s, tag)
+            gflat = g[pf + f"s{s}_grad_flat"]
+            off = 0
+            for n in names:
+                k = int(np.prod(shapes[n]))
+                ref = gflat[off:off + k]
+                off += k
+                got = grads[n].numpy().ravel()
+                assert rel_l2(got, ref) < 2e-5, (ci, s, n, rel_l2(got, ref))
+                assert rel_max(got, ref) < 2e-5, (ci, s, n)
+            o.adam_step(grads, lr)
+            assert rel_l2(o.flat(names), g[pf + f"s{s}_param_flat"]) < 1e-6, (ci, s)
+            # re-synchronise on the reference's parameters so later steps test one step each
+            o.p = {k: torch.from_numpy(v) for k, v in split_flat(g[pf + f"s{s}_param_flat"], (L, W, T, H)).items()}
+        assert o.adam_t == int(g[pf + "adam_step"])
+        assert rel_l2(orc.flat_of({k: v.numpy() for k, v in o.m.items()}, names), g[pf + "exp_avg_flat"]) < 2e-5
+        assert rel_l2(orc.flat_of({k: v.numpy() for k, v in o.v.items()}, names), g[pf + "exp_avg_sq_flat"]) < 5e-5
+        wd_lr, wd, eps_ = g[pf + "adam_kw"]
+        assert (wd, eps_) == (orc.ADAM_WD, orc.ADAM_EPS)
+
+
+def test_train_free_running(golden):
+    """No re-synchronisation: 4 consecutive steps must still land on the reference."""
+    g = golden("train")
+    for ci in range(int(g["n_cases"])):
+        pf = f"c{ci}_"
+        L, W, T, H = (int(v) for v in g[pf + "dims"])
+        lr0, nd, epochs, nb = g[pf + "hyper"]
+        epochs, nb = int(epochs), int(nb)
+        o = orc.Oracle(L, W, T, H, split_flat(g[pf + "init_flat"], (L, W, T, H)))
+        for s in range(epochs * nb):
+            eps = torch.from_numpy(g[pf + f"s{s}_raw_noise"]) * float(nd)
+            o.train_step(g[pf + f"s{s}_x0"], eps, g[pf + f"s{s}_t"], list(g[pf + f"s{s}_masks"]),
+                         o.epoch_lr(lr0, s // nb, epochs))
+        last = epochs * nb - 1
+        assert rel_l2(o.flat(synth.param_names(H)), g[pf + f"s{last}_param_flat"]) < 1e-4
+
+
+def test_sampling(golden):
+    g = golden("sampling")
+    for ci in range(int(g["n_cases"])):
+        pf = f"c{ci}_"
+        L, W, T, H = (int(v) for v in g[pf + "dims"])
+        nd = float(g[pf + "nd"])
+        o = orc.Oracle(L, W, T, H, split_flat(g[pf + "flat"], (L, W, T, H)))
+        full = o.sample(g[pf + "full_xT"], torch.from_numpy(g[pf + "full_rawz"]) * nd, g[pf + "full_masks"])
+        assert rel_max(full.numpy(), g[pf + "full_out"]) < 2e-5, ci
+        multi = o.sample(g[pf + "multi_xT"], torch.from_numpy(g[pf + "multi_rawz"]) * nd, g[pf + "multi_masks"],
+                         g[pf + "multi_Tj"])
+        assert rel_max(multi.numpy(), g[pf + "multi_out"]) < 2e-5, ci
+
+
+@pytest.mark.parametrize("name", ["ml1m", "adm", "ml100k", "ml1m_big"])
+def test_fullsize_checksums(golden, name):
+    """One full-size train step per BASELINE shape, compared through checksums."""
+    g = golden("fullsize")
+    pf = name + "_"
+    L, W, T, H, B = (int(v) for v in g[pf + "dims"])
+    lr = float(g[pf + "lr"])
+    names = synth.param_names(H)
+    init = synth.init_params(L, W, T, H, seed=1)
+    x0 = synth.synth_latents(B, L, seed=0)
+    eps, t, masks = synth.synth_train_randoms(B, L, T, 1.0, seed=2)
+    o = orc.Oracle(L, W, T, H, init)
+    loss, grads, outs, _ = o.loss_and_grads(x0, eps, t, list(masks))
+    assert abs(float(loss) - float(g[pf + "loss"])) <= 1e-5 * abs(float(g[pf + "loss"]))
+    for tag, arr in zip("PSQ", outs):
+        s, l2, smp = synth.stats(arr.numpy())
+        assert abs(l2 - g[pf + tag + "_l2"]) <= 1e-6 * g[pf + tag + "_l2"]
+        np.testing.assert_allclose(smp, g[pf + tag + "_smp"], rtol=0, atol=2e-6)
+    gl2 = np.asarray([np.sqrt((grads[n].numpy().astype(np.float64) ** 2).sum()) for n in names])
+    np.testing.assert_allclose(gl2, g[pf + "grad_l2"], rtol=1e-4)
+    o.adam_step(grads, lr)
+    newp = o.flat(names)
+    s, l2, smp = synth.stats(newp, 64)
+    assert abs(l2 - g[pf + "param_l2"]) <= 1e-6 * g[pf + "param_l2"]
+    dl2 = np.sqrt(((newp.astype(np.float64) - synth.flatten_params(init, H).astype(np.float64)) ** 2).sum())
+    assert abs(dl2 - float(g[pf + "update_l2"])) <= 2e-3 * float(g[pf + "update_l2"])
