@@ -1,0 +1,158 @@
+/*
+ * sdrm_hip.h — C ABI of libsdrm_hip.so, the MI355X (gfx950) denoising engine for SDRM.
+ *
+ * The reference (Multi-resolution-diffusion-recommender/SDRM) is pure Python on PyTorch and has
+ * no FFI layer; the boundary this library replaces is the Python call surface of
+ * /root/reference/train_SDRM.py as consumed by main.py:148-175 and
+ * hyperparameter_search.py:147,386,691.  Each entry point below cites the
+ * reference lines whose device work it replaces.  The Python shim that keeps the
+ * reference's names (`train_SDRM`, `sample_ddpm`, `SDRM.forward`, ...) lives in
+ * sdrm_amd/train_SDRM.py and binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - Every `const float*` / `float*` / `const int64_t*` / `const uint8_t*` argument whose name does
+ *    not end in `_host` is a DEVICE pointer owned by the caller (e.g. `tensor.data_ptr()` of a
+ *    contiguous ROCm torch tensor).  The library owns only handle-internal buffers and never
+ *    allocates in a step call.
+ *  - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream).  All work is
+ *    enqueued on it and nothing synchronises unless stated.
+ *  - All arithmetic is fp32; `t` / `Tj` are int64 as in the reference (`torch.randint`, :327).
+ *  - Return value: 0 on success, negative `sdrm_status` otherwise; never throws.  The message of the
+ *    last failure on a handle is returned by sdrm_last_error().
+ *  - A handle is not thread-safe; distinct handles are independent.
+ *
+ * Parameter order of every "flat" vector (P floats) = SDRM.named_parameters() of the reference
+ * (train_SDRM.py:86-95):
+ *   emb_layer.weight[T,T] emb_layer.bias[T] dnn.0.weight[W,L+T] dnn.0.bias[W] dnn.1.weight[1]
+ *   (H>=1: dnn.2.weight[W,W] dnn.2.bias[W] dnn.3.weight[1])  dnn.{2+2H}.weight[L,W] dnn.{2+2H}.bias[L]
+ * The H hidden layers share ONE weight/bias/slope (train_SDRM.py:94, quirk Q1).
+ */
+#ifndef SDRM_HIP_H
+#define SDRM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sdrm_engine sdrm_engine;
+
+enum sdrm_status {
+  SDRM_OK = 0,
+  SDRM_ERR_ARG = -1,    /* null pointer / bad enum */
+  SDRM_ERR_SHAPE = -2,  /* rows > max_rows, L/W/T/H outside the supported envelope */
+  SDRM_ERR_HIP = -3,    /* a HIP runtime call failed */
+  SDRM_ERR_STATE = -4,  /* call order violated (e.g. backward before forward) */
+  SDRM_ERR_NOMEM = -5
+};
+
+/* Where the randomness of a call comes from (SURVEY.md §8b "two RNG modes"). */
+enum sdrm_rng_mode {
+  SDRM_RNG_EXPLICIT = 0, /* caller supplies noise / t / dropout keep-masks / z (parity mode) */
+  SDRM_RNG_PHILOX = 1    /* counter-based Philox4x32-10 keyed by (seed, step, GLOBAL row, column) */
+};
+
+/* Explicit randoms of one train step.  Replaces the draws at train_SDRM.py:326-327 and the three
+ * F.dropout masks of :100 (one per forward pass, order P, S, Q — :331, :193, :195). */
+typedef struct sdrm_train_randoms {
+  const float* noise;    /* [B,L] eps, ALREADY multiplied by noise_divider (:326) */
+  const int64_t* t;      /* [B] timesteps in 1..T (:327) */
+  const uint8_t* keep;   /* [3,B,L] 1 = element survives dropout (then scaled by 2) */
+} sdrm_train_randoms;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Builds an engine for an eps-predictor SDRM(N_ITEMS=L, EMB_DIM=T, LATENT_DIM=W, n_hidden_layers=H)
+ * (train_SDRM.py:86-95, :305) able to process up to max_rows rows per call, with Adam state
+ * (train_SDRM.py:309) and the DDPM schedule for beta1=1e-4, beta2=0.02 (train_SDRM.py:275-276,
+ * 300-303).  Parameters start at zero: call sdrm_set_params.  Envelope: 1<=L,W<=4096, 2<=T<=1024,
+ * 0<=H<=16. */
+int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_engine** out);
+int sdrm_destroy(sdrm_engine* e);
+const char* sdrm_last_error(const sdrm_engine* e);
+int64_t sdrm_param_count(const sdrm_engine* e);
+
+/* ---- schedule (train_SDRM.py:296-303; module globals b_t/a_t/ab_t, quirk Q10) ---------------- */
+int sdrm_set_schedule(sdrm_engine* e, float beta1, float beta2);
+/* Copies beta, alpha, alpha-bar ([T+1] each) to HOST arrays. */
+int sdrm_get_schedule(const sdrm_engine* e, float* beta_host, float* alpha_host, float* alphabar_host);
+
+/* ---- parameters / optimiser state (nn.Module.state_dict / torch.optim.Adam state) ------------ */
+int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream);
+int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream);
+/* Gradient of the last backward, flat [P] (what autograd leaves in p.grad after :336). */
+int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream);
+/* Adam first/second moments, flat [P] each, and the global step counter (Q8). */
+int sdrm_get_adam_state(const sdrm_engine* e, float* exp_avg, float* exp_avg_sq, int64_t* step_host, void* stream);
+int sdrm_set_adam_state(sdrm_engine* e, const float* exp_avg, const float* exp_avg_sq, int64_t step, void* stream);
+int sdrm_adam_reset(sdrm_engine* e, void* stream);
+
+/* ---- training step, split in the three phases the user-sharded (multi-GPU) step needs --------- *
+ * Replaces train_SDRM.py:326-337 for one batch of B rows (this rank's shard).
+ *
+ * (1) sdrm_train_forward: q_sample (:203,:328) + the three eps-net forwards P=f(x_pert,t),
+ *     S=f(x0,t), Q=f(x0+0.1*eps,t) (:331,:193-195) + the rank-local partial sums of the loss
+ *     (:196-198): sums[0..4] = { sum D^2, sum (R-S)^2, sum R, sum R^2, count } in float64, where
+ *     R = P-x0, D = (Q-S)/mu^2 - R.  Multi-GPU callers all-reduce(sum) these 5 doubles.
+ *     row0 = global index of this shard's first row (keys the Philox streams; 0 on one GPU),
+ *     seed/step key the PHILOX mode; `rnd` is used in EXPLICIT mode (may be NULL in PHILOX mode).
+ * (2) sdrm_train_backward: loss value (:198) and closed-form gradient seeds from the GLOBAL sums,
+ *     backward through the three passes, gradient accumulation over passes and over the H shared
+ *     hidden applications; writes this rank's flat gradient [P] to `grad` (device; may be NULL to
+ *     keep it internal) and the global loss to `loss` (device float; may be NULL).  Multi-GPU
+ *     callers all-reduce(sum) `grad`.
+ * (3) sdrm_adam_step: torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-4) with
+ *     coupled L2 (:309, :337), on `grad` (device, flat [P]; NULL = the internal gradient).
+ *     lr is the caller's per-epoch value DIFF_LR*(1-ep/EPOCHS) (:316).
+ */
+int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode,
+                       const sdrm_train_randoms* rnd, uint64_t seed, uint64_t step, float noise_divider,
+                       double* sums, void* stream);
+int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream);
+int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream);
+/* Single-GPU convenience: (1)+(2)+(3) back to back on `stream`. */
+int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,
+                    uint64_t seed, uint64_t step, float noise_divider, float* loss, void* stream);
+/* Outputs of the last sdrm_train_forward: P,S,Q as [3,B,L] (parity tests). */
+int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream);
+
+/* ---- plain forward: SDRM.forward(x, t) (train_SDRM.py:97-103), dropout always on (Q2) ---------- *
+ * keep [n,L] (EXPLICIT) or Philox(seed, step, row0+row, col).  Used by callers that run their own
+ * sampler (hyperparameter_search.py:67,78). */
+int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mode, const uint8_t* keep,
+                 uint64_t seed, uint64_t step, int64_t row0, float* out, void* stream);
+
+/* ---- reverse sampling: sample_ddpm latent loop (train_SDRM.py:37-59) + denoise_add_noise (:20-25) *
+ * Runs i = T..1 over n rows and writes the final latents x_0 to out[n,L] (the caller then applies
+ * vae.decode, :49/:61).  Tj == NULL -> full resolution (:50-59).  Tj != NULL -> multi-resolution
+ * (:37-48): row j runs i = Tj[j]..1; rows are independent, so this equals the reference's per-user
+ * batch-1 loop (Q11).  EXPLICIT mode: xT[n,L] start noise (:38/:51), z[T+1,n,L] with z[i] the noise
+ * injected at step i ALREADY multiplied by noise_divider (z[1] is ignored: no noise at i==1, Q9),
+ * keep[T+1,n,L] dropout keep-masks per step.  PHILOX mode: all of those (and Tj when
+ * `multires` != 0) are drawn on device; Tj_out (device int64 [n], may be NULL) receives the drawn
+ * start steps. */
+int sdrm_sample(sdrm_engine* e, int n, float noise_divider, int multires, int mode, const float* xT,
+                const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,
+                int64_t row0, float* out, int64_t* Tj_out, void* stream);
+
+/* One reverse step on caller-owned state, for callers that drive the loop themselves:
+ * x <- denoise_add_noise(x, i, f(x, i), z) (train_SDRM.py:56-59).  z may be NULL (= 0, the i==1 case). */
+int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, const uint8_t* keep, void* stream);
+
+/* q_sample alone: perturb_input(x, t, noise) (train_SDRM.py:202-203). */
+int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const float* noise, int n, float* out,
+                       void* stream);
+
+/* ---- introspection for bench.py / profiling ---------------------------------------------------- */
+/* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
+const char* sdrm_build_info(void);
+/* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),
+ * A^T * B (variant 2, A is [K,M], B is [K,N]) through the same MFMA kernel the engine uses.  All
+ * dims must be multiples of 32 and M (variant 0/1) resp. K (variant 2) a multiple of 128. */
+int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRM_HIP_H */

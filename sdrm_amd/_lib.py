@@ -1,0 +1,79 @@
+"""ctypes binding of libsdrm_hip.so (C ABI in include/sdrm_hip.h).
+
+There is NO fallback: if the library cannot be built or loaded, `load()` raises — the product path
+never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_LIB = None
+
+c_void_p, c_int, c_int64, c_uint64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+
+
+class TrainRandoms(C.Structure):
+    _fields_ = [("noise", c_void_p), ("t", c_void_p), ("keep", c_void_p)]
+
+
+# name -> (restype, argtypes); mirrors include/sdrm_hip.h one to one
+SIGNATURES = {
+    "sdrm_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_void_p)]),
+    "sdrm_destroy": (c_int, [c_void_p]),
+    "sdrm_last_error": (C.c_char_p, [c_void_p]),
+    "sdrm_param_count": (c_int64, [c_void_p]),
+    "sdrm_set_schedule": (c_int, [c_void_p, c_float, c_float]),
+    "sdrm_get_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdrm_set_params": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_get_params": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_get_grads": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_get_adam_state": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int64), c_void_p]),
+    "sdrm_set_adam_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sdrm_adam_reset": (c_int, [c_void_p, c_void_p]),
+    "sdrm_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, C.POINTER(TrainRandoms), c_uint64,
+                                   c_uint64, c_float, c_void_p, c_void_p]),
+    "sdrm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdrm_adam_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
+    "sdrm_train_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, C.POINTER(TrainRandoms), c_uint64, c_uint64,
+                                c_float, c_void_p, c_void_p]),
+    "sdrm_get_train_outputs": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_uint64, c_uint64, c_int64,
+                             c_void_p, c_void_p]),
+    "sdrm_sample": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
+                            c_uint64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sdrm_reverse_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdrm_perturb_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sdrm_build_info": (C.c_char_p, []),
+    "sdrm_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+}
+
+RNG_EXPLICIT, RNG_PHILOX = 0, 1
+STATUS = {0: "SDRM_OK", -1: "SDRM_ERR_ARG", -2: "SDRM_ERR_SHAPE", -3: "SDRM_ERR_HIP", -4: "SDRM_ERR_STATE",
+          -5: "SDRM_ERR_NOMEM"}
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load(build_if_missing: bool = True):
+    """Loads (building first if needed) the HIP library; raises RuntimeError if that is impossible."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _build.build_library()
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise RuntimeError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib

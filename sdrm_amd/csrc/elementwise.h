@@ -1,0 +1,471 @@
+// Elementwise / reduction / optimiser kernels of the SDRM denoising path (gfx950).
+// Reference lines are into /root/reference/train_SDRM.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "philox.h"
+
+namespace sdrm {
+
+constexpr float MU = 0.1f;          // score_matching_loss(..., mu=.1), :333
+constexpr float MU2 = 0.01f;        // mu ** 2, :196
+
+// ---------------------------------------------------------------------------------------------
+// Train-step staging: q_sample (:203) + the three dropout-ed inputs (:100) + one-hot(t) columns.
+//   U[0*B + r] = 2*keep1 * (sqrt(abar[t]) x0 + (1-abar[t]) eps)      pass P (:328,:331)
+//   U[1*B + r] = 2*keep2 * x0                                         pass S (:193)
+//   U[2*B + r] = 2*keep3 * (x0 + 0.1 eps)                             pass Q (:194-195)
+// columns [L,LP) zero, columns LP + t = 1 (one-hot, multiplies the per-step table C0^T stored in the
+// trailing columns of W0c).  Rows [3B, MP) are zero-filled.
+struct PrepTrainArgs {
+  const float* x0; const float* noise; const int64_t* t; const uint8_t* keep;
+  const float* sqrt_ab; const float* one_minus_ab;
+  float* U; int* tdev;
+  int B, L, LP, K0, T, MP;
+  int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
+};
+
+__global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
+  const int r = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;  // column pair
+  const int c = 2 * q;
+  if (c >= a.K0) return;
+  if (r >= a.B) {  // zero pad rows
+    const int row = 3 * a.B + (r - a.B);
+    if (row < a.MP) *reinterpret_cast<float2*>(a.U + (size_t)row * a.K0 + c) = make_float2(0.f, 0.f);
+    return;
+  }
+  int tt;
+  if (a.mode == 0) {
+    tt = (int)a.t[r];
+  } else {
+    const U4 w = philox4x32_10((uint32_t)(a.row0 + r), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
+    tt = 1 + (int)bounded(w.x, (uint32_t)a.T);
+  }
+  tt = min(max(tt, 0), a.T);
+  if (q == 0) a.tdev[r] = tt;
+  float2 oP = make_float2(0.f, 0.f), oS = oP, oQ = oP;
+  if (c < a.LP) {
+    if (c < a.L) {
+      const float sa = a.sqrt_ab[tt], om = a.one_minus_ab[tt];
+      float e[2] = {0.f, 0.f};
+      uint32_t bits = 0;
+      if (a.mode != 0) {
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)q, PURPOSE_TRAIN_ELEM, a.step, a.seed_lo,
+                                   a.seed_hi);
+        box_muller(w.x, w.y, e[0], e[1]);
+        e[0] *= a.nd; e[1] *= a.nd;
+        bits = w.z;
+      }
+      float vP[2] = {0.f, 0.f}, vS[2] = {0.f, 0.f}, vQ[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cc = c + j;
+        if (cc < a.L) {
+          const size_t idx = (size_t)r * a.L + cc;
+          const float x = a.x0[idx];
+          bool k1, k2, k3;
+          float ee;
+          if (a.mode == 0) {
+            ee = a.noise[idx];
+            const size_t BL = (size_t)a.B * a.L;
+            k1 = a.keep[idx] != 0; k2 = a.keep[BL + idx] != 0; k3 = a.keep[2 * BL + idx] != 0;
+          } else {
+            ee = e[j];
+            const uint32_t bb = bits >> (8 * j);
+            k1 = bb & 1u; k2 = (bb >> 1) & 1u; k3 = (bb >> 2) & 1u;
+          }
+          const float xp = sa * x + om * ee;
+          const float xq = x + MU * ee;
+          vP[j] = k1 ? 2.f * xp : 0.f;
+          vS[j] = k2 ? 2.f * x : 0.f;
+          vQ[j] = k3 ? 2.f * xq : 0.f;
+        }
+      }
+      oP = make_float2(vP[0], vP[1]); oS = make_float2(vS[0], vS[1]); oQ = make_float2(vQ[0], vQ[1]);
+    }
+  } else {
+    const int h = c - a.LP;  // one-hot region
+    const float2 oh = make_float2(h == tt ? 1.f : 0.f, (h + 1) == tt ? 1.f : 0.f);
+    oP = oh; oS = oh; oQ = oh;
+  }
+  *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = oP;
+  *reinterpret_cast<float2*>(a.U + (size_t)(a.B + r) * a.K0 + c) = oS;
+  *reinterpret_cast<float2*>(a.U + (size_t)(2 * a.B + r) * a.K0 + c) = oQ;
+}
+
+// Staging for a plain forward / reverse step on caller rows: U = 2*keep*x | one-hot(t).
+struct PrepFwdArgs {
+  const float* x; const int64_t* t; int t_uniform; const uint8_t* keep;
+  float* U; int n, L, LP, K0, T, MP;
+  int mode; uint32_t seed_lo, seed_hi, step; int64_t row0;
+};
+
+__global__ __launch_bounds__(256) void k_prep_forward(const PrepFwdArgs a) {
+  const int r = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int c = 2 * q;
+  if (c >= a.K0 || r >= a.MP) return;
+  float2 o = make_float2(0.f, 0.f);
+  if (r < a.n) {
+    int tt = a.t ? (int)a.t[r] : a.t_uniform;
+    tt = min(max(tt, 0), a.T);
+    if (c < a.LP) {
+      uint32_t bits = 0;
+      if (a.mode != 0 && c < a.L) {
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)q, PURPOSE_FORWARD, a.step, a.seed_lo, a.seed_hi);
+        bits = w.z;
+      }
+      float v[2] = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cc = c + j;
+        if (cc < a.L) {
+          const size_t idx = (size_t)r * a.L + cc;
+          const bool k = (a.mode == 0) ? (a.keep[idx] != 0) : (((bits >> (8 * j)) & 1u) != 0);
+          v[j] = k ? 2.f * a.x[idx] : 0.f;
+        }
+      }
+      o = make_float2(v[0], v[1]);
+    } else {
+      const int h = c - a.LP;
+      o = make_float2(h == tt ? 1.f : 0.f, (h + 1) == tt ? 1.f : 0.f);
+    }
+  }
+  *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-step time-embedding tables (only T+1 distinct timesteps exist):
+//   E[t]  = temb[t] * We^T + be                    (:98-99)
+//   C0[t] = E[t] * W0[:, L:]^T                     (the emb part of dnn.0, :101-102)
+// written as C0^T into the trailing columns of the padded layer-0 weight W0c[w][LP + t]; for sampling
+// (all rows share t) also B0tab[t][w] = b0[w] + C0[t][w].
+struct EmbTabArgs {
+  const float* temb; const float* We; const float* be; const float* W0; const float* b0;
+  float* Etab; float* W0c; float* B0tab;
+  int L, W, T, LP, WP, K0;
+};
+
+__global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
+  extern __shared__ float sh[];  // [2*T]: temb row, E row
+  const int t = blockIdx.x;
+  float* tr = sh;
+  float* er = sh + a.T;
+  for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
+    float s = a.be[j];
+    const float* wr = a.We + (size_t)j * a.T;
+    for (int i = 0; i < a.T; ++i) s = fmaf(wr[i], tr[i], s);
+    er[j] = s;
+    a.Etab[(size_t)t * a.T + j] = s;
+  }
+  __syncthreads();
+  const int ldw = a.L + a.T;
+  for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
+    float s = 0.f;
+    if (w < a.W) {
+      const float* wr = a.W0 + (size_t)w * ldw + a.L;
+      for (int j = 0; j < a.T; ++j) s = fmaf(wr[j], er[j], s);
+    }
+    a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
+    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss partial sums (:196-198): R = P - x0, D = (Q-S)/mu^2 - R.
+struct LossArgs {
+  const float* Y; const float* x0; int B, L, LP;
+  double* part;   // [gridDim.x][4]
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(256) void k_loss_partials(const LossArgs a) {
+  __shared__ double sh[4];
+  double sD = 0, sC = 0, sR = 0, sR2 = 0;
+  const size_t total = (size_t)a.B * a.L;
+  const size_t BLP = (size_t)a.B * a.LP;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / a.L), c = (int)(i - (size_t)r * a.L);
+    const size_t yi = (size_t)r * a.LP + c;
+    const float P = a.Y[yi], S = a.Y[BLP + yi], Q = a.Y[2 * BLP + yi];
+    const float R = P - a.x0[i];
+    const float D = (Q - S) / MU2 - R;
+    const float RS = R - S;
+    sD += (double)D * D; sC += (double)RS * RS; sR += R; sR2 += (double)R * R;
+  }
+  const double tD = block_sum(sD, sh), tC = block_sum(sC, sh), tR = block_sum(sR, sh), tR2 = block_sum(sR2, sh);
+  if (threadIdx.x == 0) {
+    double* o = a.part + 4 * (size_t)blockIdx.x;
+    o[0] = tD; o[1] = tC; o[2] = tR; o[3] = tR2;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_loss_sums(const double* part, int nblk, double count, double* sums) {
+  __shared__ double sh[4];
+  double v[4] = {0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nblk; i += blockDim.x)
+    for (int j = 0; j < 4; ++j) v[j] += part[4 * (size_t)i + j];
+  for (int j = 0; j < 4; ++j) {
+    const double s = block_sum(v[j], sh);
+    if (threadIdx.x == 0) sums[j] = s;
+  }
+  if (threadIdx.x == 0) sums[4] = count;
+}
+
+// Loss value and closed-form gradient seeds, times tanh' = 1 - y^2.
+struct SeedArgs {
+  const double* sums; const float* Y; const float* x0; float* dY; float* loss;
+  int B, L, LP, MP;
+};
+
+__global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.LP) return;
+  if (r >= a.B) {
+    const int row = 3 * a.B + (r - a.B);
+    if (row < a.MP) a.dY[(size_t)row * a.LP + c] = 0.f;
+    return;
+  }
+  const double N = a.sums[4];
+  const double A = a.sums[0] / N, C = a.sums[1] / N, Rbar = a.sums[2] / N;
+  const double V = (a.sums[3] - N * Rbar * Rbar) / (N - 1.0);
+  const double den = 1e-8 + V;
+  const double k = 0.5 / den;
+  if (r == 0 && c == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);
+  const size_t BLP = (size_t)a.B * a.LP;
+  const size_t yi = (size_t)r * a.LP + c;
+  float gP = 0.f, gS = 0.f, gQ = 0.f;
+  if (c < a.L) {
+    const float cD = (float)(2.0 * k / N);
+    const float cV = (float)(-(0.5 * (A + C) / (den * den)) * 2.0 / (N - 1.0));
+    const float P = a.Y[yi], S = a.Y[BLP + yi], Q = a.Y[2 * BLP + yi];
+    const float R = P - a.x0[(size_t)r * a.L + c];
+    const float D = (Q - S) / MU2 - R;
+    const float gD = cD * D;
+    const float gC = cD * (R - S);
+    const float gV = cV * (R - (float)Rbar);
+    gP = (-gD + gC + gV) * (1.f - P * P);
+    gQ = (gD / MU2) * (1.f - Q * Q);
+    gS = (-gD / MU2 - gC) * (1.f - S * S);
+  }
+  a.dY[yi] = gP; a.dY[BLP + yi] = gS; a.dY[2 * BLP + yi] = gQ;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding-path backward from dC0 (the one-hot columns of the layer-0 weight gradient):
+//   dC0[t][w] = sum_s slab0[s][w][LP+t] ;  dE[t] = dC0[t] * W0[:, L:]
+struct EmbBwdArgs {
+  const float* slab0; size_t slab_stride; int S;
+  const float* W0; const float* Etab; const float* temb;
+  float* dC0; float* dE; float* g; int64_t off_we, off_be, off_w0;
+  int L, W, T, LP, K0;
+};
+
+__global__ __launch_bounds__(256) void k_emb_bwd1(const EmbBwdArgs a) {
+  extern __shared__ float sh[];  // [W]
+  const int t = blockIdx.x;
+  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < a.S; ++k) s += a.slab0[(size_t)k * a.slab_stride + (size_t)w * a.K0 + a.LP + t];
+    sh[w] = s;
+    a.dC0[(size_t)t * a.W + w] = s;
+  }
+  __syncthreads();
+  const int ldw = a.L + a.T;
+  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < a.W; ++w) s = fmaf(sh[w], a.W0[(size_t)w * ldw + a.L + j], s);
+    a.dE[(size_t)t * a.T + j] = s;
+  }
+}
+
+//   dW0[:, L+j] = sum_t dC0[t][w] E[t][j] ; dWe[j][i] = sum_t dE[t][j] temb[t][i] ; dbe[j] = sum_t dE[t][j]
+__global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
+  const int n1 = a.W * a.T, n2 = a.T * a.T, n3 = a.T;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) {
+    const int w = i / a.T, j = i - w * a.T;
+    float s = 0.f;
+    for (int t = 0; t <= a.T; ++t) s = fmaf(a.dC0[(size_t)t * a.W + w], a.Etab[(size_t)t * a.T + j], s);
+    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = s;
+  } else if (i < n1 + n2) {
+    const int k = i - n1;
+    const int j = k / a.T, ii = k - j * a.T;
+    float s = 0.f;
+    for (int t = 0; t <= a.T; ++t) s = fmaf(a.dE[(size_t)t * a.T + j], a.temb[(size_t)t * a.T + ii], s);
+    a.g[a.off_we + k] = s;
+  } else if (i < n1 + n2 + n3) {
+    const int j = i - n1 - n2;
+    float s = 0.f;
+    for (int t = 0; t <= a.T; ++t) s += a.dE[(size_t)t * a.T + j];
+    a.g[a.off_be + j] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slab reduction into the flat gradient, and Adam + re-pack of the padded compute copies.
+struct Job {
+  int64_t flat_off;   // offset of the tensor in the flat vectors
+  int rows, cols;     // logical shape; flat row stride = flat_ld
+  int flat_ld;
+  int ncols;          // columns [0,ncols) of each row are covered by this job (dnn.0.weight: L of L+T)
+  const float* src; int src_ld; size_t slab_stride; int nslabs;   // finalize source (padded slabs)
+  int inner;          // >1: scalar job, sum src[k*slab_stride + q] over k<nslabs, q<inner (slope partials)
+  float* dst; int dst_ld;                                          // compute copy (may be null)
+};
+constexpr int MAX_JOBS = 12;
+struct JobTable { Job j[MAX_JOBS]; int n; };
+
+__global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab, float* g) {
+  const Job& jb = tab.j[blockIdx.y];
+  if (jb.src == nullptr) return;
+  const int64_t total = (int64_t)jb.rows * jb.ncols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / jb.ncols), c = (int)(i - (int64_t)r * jb.ncols);
+    const float* s = jb.src + (size_t)r * jb.src_ld + c;
+    float acc = 0.f;
+    for (int k = 0; k < jb.nslabs; ++k)
+      for (int q = 0; q < jb.inner; ++q) acc += s[(size_t)k * jb.slab_stride + q];
+    g[jb.flat_off + (int64_t)r * jb.flat_ld + c] = acc;
+  }
+}
+
+// torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-4), coupled L2 (:309, Q8):
+//   g += wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+struct AdamArgs {
+  float* p; float* m; float* v; const float* g;
+  float step_size, bc2_sqrt, b1, b2, eps, wd;
+  int update;   // 0: only re-pack compute copies from p (set_params)
+};
+
+__global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs a) {
+  const Job& jb = tab.j[blockIdx.y];
+  const int64_t total = (int64_t)jb.rows * jb.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
+    const int64_t fi = jb.flat_off + (int64_t)r * jb.flat_ld + c;
+    float w = a.p[fi];
+    if (a.update) {
+      const float gg = a.g[fi] + a.wd * w;
+      const float mm = a.b1 * a.m[fi] + (1.f - a.b1) * gg;
+      const float vv = a.b2 * a.v[fi] + (1.f - a.b2) * gg * gg;
+      a.m[fi] = mm; a.v[fi] = vv;
+      const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+      w = w - a.step_size * (mm / denom);
+      a.p[fi] = w;
+    }
+    if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampling helpers.
+struct SampleInitArgs {
+  const float* xT; const uint8_t* keep; const int64_t* Tj_in; int64_t* Tj_dev; int64_t* Tj_out;
+  float* X; float* U; int n, L, LP, K0, MP, T, i_start;
+  int mode, multires; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
+};
+
+__global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
+  const int r = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int c = 2 * q;
+  if (c >= a.LP || r >= a.MP) return;
+  float x[2] = {0.f, 0.f}, u[2] = {0.f, 0.f};
+  if (r < a.n) {
+    if (q == 0 && a.Tj_dev) {
+      int64_t tj;
+      if (a.mode == 0) tj = a.Tj_in[r];
+      else {
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), 0u, PURPOSE_SAMPLE_TJ, a.call_id, a.seed_lo, a.seed_hi);
+        tj = 1 + (int64_t)bounded(w.x, (uint32_t)max(a.T - 1, 1));  // np.random.randint(1, T), :42
+      }
+      a.Tj_dev[r] = tj;
+      if (a.Tj_out) a.Tj_out[r] = tj;
+    }
+    if (c < a.L) {
+      uint32_t bits = 0;
+      float nrm[2] = {0.f, 0.f};
+      if (a.mode != 0) {
+        const uint32_t grow = (uint32_t)(a.row0 + r);
+        const U4 w = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_XT, a.call_id, a.seed_lo, a.seed_hi);
+        box_muller(w.x, w.y, nrm[0], nrm[1]);
+        const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)a.i_start << 8), a.call_id,
+                                    a.seed_lo, a.seed_hi);
+        bits = w2.z;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int cc = c + j;
+        if (cc < a.L) {
+          const size_t idx = (size_t)r * a.L + cc;
+          x[j] = (a.mode == 0) ? a.xT[idx] : nrm[j];
+          const bool k = (a.mode == 0) ? (a.keep[idx] != 0) : (((bits >> (8 * j)) & 1u) != 0);
+          u[j] = k ? 2.f * x[j] : 0.f;
+        }
+      }
+    }
+  }
+  *reinterpret_cast<float2*>(a.X + (size_t)r * a.LP + c) = make_float2(x[0], x[1]);
+  *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = make_float2(u[0], u[1]);
+}
+
+__global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L) {
+  const size_t total = (size_t)n * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / L), c = (int)(i - (size_t)r * L);
+    dst[i] = src[(size_t)r * ld + c];
+  }
+}
+
+// [3][B][LP] padded outputs -> [3][B][L]
+__global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L, int LP, float* dst) {
+  const size_t total = (size_t)3 * B * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / L; const int c = (int)(i - r * L);
+    dst[i] = Y[r * LP + c];
+  }
+}
+
+// x <- (x - eps_hat * c1) / sqrt(alpha_i) + sqrt(beta_i) * z   (denoise_add_noise, :20-25)
+__global__ __launch_bounds__(256) void k_reverse_apply(float* x, const float* Y, int ldy, const float* z, int n, int L,
+                                                       float c1, float sqrt_alpha, float sqrt_beta) {
+  const size_t total = (size_t)n * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / L), c = (int)(i - (size_t)r * L);
+    const float e = Y[(size_t)r * ldy + c];
+    const float zz = z ? z[i] : 0.f;
+    x[i] = (x[i] - e * c1) / sqrt_alpha + sqrt_beta * zz;
+  }
+}
+
+// perturb_input (:202-203)
+__global__ __launch_bounds__(256) void k_perturb(const float* x, const int64_t* t, const float* noise,
+                                                 const float* sqrt_ab, const float* one_minus_ab, int n, int L, int T,
+                                                 float* out) {
+  const size_t total = (size_t)n * L;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / L);
+    const int tt = min(max((int)t[r], 0), T);
+    out[i] = sqrt_ab[tt] * x[i] + one_minus_ab[tt] * noise[i];
+  }
+}
+
+}  // namespace sdrm

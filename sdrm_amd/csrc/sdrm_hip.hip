@@ -1,0 +1,678 @@
+// libsdrm_hip.so — C ABI (include/sdrm_hip.h) over the gfx950 kernels in gemm.h / elementwise.h.
+// Host logic only: buffer ownership, launch orchestration of the train step / sampler, error codes.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sdrm_hip.h"
+#include "elementwise.h"
+#include "gemm.h"
+
+using namespace sdrm;
+
+namespace {
+
+constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
+constexpr int TARGET_BLOCKS = 512; // work-groups a wgrad launch aims for (2 per CU)
+constexpr int LOSS_BLOCKS = 256;
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct sdrm_engine {
+  int L, W, T, H, max_rows, device;
+  int LP, WP, TP, K0, MPmax;
+  int64_t P;
+  int64_t off_we, off_be, off_w0, off_b0, off_a0, off_wh, off_bh, off_ah, off_wo, off_bo;
+  // flat master copies
+  float *p = nullptr, *m = nullptr, *v = nullptr, *g = nullptr;
+  // padded compute copies
+  float *W0c = nullptr, *b0c = nullptr, *Whc = nullptr, *bhc = nullptr, *Woc = nullptr, *boc = nullptr;
+  float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
+  float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
+  float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *dB = nullptr, *X = nullptr;
+  float *slab0 = nullptr, *slabH = nullptr, *slabO = nullptr, *db0s = nullptr, *dbHs = nullptr, *dbOs = nullptr;
+  float *alpha_part = nullptr;
+  int alpha_part_stride = 0;
+  double *loss_part = nullptr, *sums = nullptr;
+  float *dC0 = nullptr, *dE = nullptr;
+  int *tdev = nullptr;
+  int64_t *Tj_dev = nullptr;
+  std::vector<float> h_beta, h_alpha, h_alphabar;
+  int64_t adam_t = 0;
+  // state of the last train_forward
+  int cur_B = 0, cur_MP = 0;
+  const float* cur_x0 = nullptr;
+  bool fwd_done = false;
+  int last_S = 1, last_dgrad_blocks = 0;
+  std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(e, call)                                                                   \
+  do {                                                                                     \
+    hipError_t _st = (call);                                                               \
+    if (_st != hipSuccess) {                                                               \
+      (e)->err = std::string(#call) + ": " + hipGetErrorString(_st);                       \
+      return SDRM_ERR_HIP;                                                                 \
+    }                                                                                      \
+  } while (0)
+
+int fail(sdrm_engine* e, int code, const std::string& msg) {
+  if (e) e->err = msg;
+  return code;
+}
+
+template <typename Tp>
+hipError_t dalloc(Tp** p, size_t n) {
+  hipError_t st = hipMalloc((void**)p, n * sizeof(Tp));
+  if (st != hipSuccess) return st;
+  return hipMemset(*p, 0, n * sizeof(Tp));
+}
+
+float* pre_buf(sdrm_engine* e, int k) { return e->pre + (size_t)k * e->MPmax * e->WP; }
+const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? e->off_a0 : e->off_ah); }
+
+// ---- GEMM launch helpers ----------------------------------------------------------------------
+template <int LA, int LB, int XA, int XB, int EPI>
+hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  a.tiles_n = tiles_n;
+  a.nblocks = tiles_m * tiles_n;
+  dim3 grid(a.nblocks, 1, splits);
+  hipLaunchKernelGGL((gemm_kernel<LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
+  return hipGetLastError();
+}
+
+// forward Linear: C[M,N] = act(xf(A)[M,K] * Wc[N,K]^T + bias)
+template <int XA, int EPI>
+hipError_t gemm_forward(GemmArgs a, const float* A, int lda, const float* Wc, int ldw, int M, int N, int K,
+                        hipStream_t st) {
+  a.A = A; a.lda = lda; a.limA = M;
+  a.B = Wc; a.ldb = ldw; a.limB = N;
+  a.K = K; a.kchunk = K;
+  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st);
+}
+
+// dgrad: C[M,Kin] = (dC[M,Nout] * Wc[Nout,Kin]) * prelu'(aux)
+hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* Wc, int ldw, int M, int Nout, int Kin,
+                      float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st) {
+  GemmArgs a{};
+  a.A = dC; a.lda = lddc; a.limA = M;
+  a.B = Wc; a.ldb = ldw; a.limB = Kin;
+  a.C = out; a.ldc = e->WP;
+  a.K = Nout; a.kchunk = Nout;
+  a.aux = aux; a.ldaux = e->WP; a.slopeE = slopeE; a.slope_partial = partial;
+  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st);
+}
+
+// wgrad: slab[s][Nout,Kin] = dC[rows s][.,Nout]^T * xf(Act)[rows s][., Kin] ; dbias[s][Nout] = column sums of dC
+template <int XB>
+hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int ldact, int Kin, const float* slopeB,
+                      int Mrows, int S, int kchunk, float* slab, float* dbias, hipStream_t st) {
+  GemmArgs a{};
+  a.A = dC; a.lda = lddc; a.limA = Nout;
+  a.B = Act; a.ldb = ldact; a.limB = Kin;
+  a.C = slab; a.ldc = Kin;
+  a.K = Mrows; a.kchunk = kchunk;
+  a.slopeB = slopeB;
+  a.slab_stride = (size_t)Nout * Kin;
+  a.dbias = dbias; a.dbias_stride = Nout;
+  return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st);
+}
+
+void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
+  const int tiles = ((Nout + BM - 1) / BM) * ((Kin + BN - 1) / BN);
+  int want = (TARGET_BLOCKS + tiles - 1) / tiles;
+  int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
+  if (max_by_rows < 1) max_by_rows = 1;
+  S = want < 1 ? 1 : want;
+  if (S > S_MAX) S = S_MAX;
+  if (S > max_by_rows) S = max_by_rows;
+  kchunk = round_up((Mrows + S - 1) / S, BK);
+  S = (Mrows + kchunk - 1) / kchunk;
+}
+
+void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks) {
+  const int L = e->L, W = e->W, T = e->T, H = e->H;
+  int n = 0;
+  auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, const float* src, int src_ld,
+                 size_t slab_stride, int nslabs, float* dst, int dst_ld, int inner = 1) {
+    Job& j = tab.j[n++];
+    j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
+    j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
+    j.inner = inner;
+  };
+  // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
+  add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
+  add(e->off_w0, W, L + T, L + T, L, e->slab0, e->K0, (size_t)e->WP * e->K0, S0, e->W0c, e->K0);
+  add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
+  // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
+  add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
+  if (H >= 1) {
+    add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP);
+    add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
+    add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
+        dgrad_blocks);
+  }
+  add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP);
+  add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
+  tab.n = n;
+}
+
+int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStream_t st) {
+  JobTable tab;
+  build_jobs(e, tab, 1, 1, 1, 1);
+  AdamArgs a{};
+  a.p = e->p; a.m = e->m; a.v = e->v; a.g = grad ? grad : e->g;
+  a.b1 = 0.9f; a.b2 = 0.999f; a.eps = 1e-8f; a.wd = 1e-4f; a.update = update;
+  if (update) {
+    const double k = (double)e->adam_t;
+    const double bc1 = 1.0 - std::pow(0.9, k), bc2 = 1.0 - std::pow(0.999, k);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)std::sqrt(bc2);
+  }
+  dim3 grid(128, tab.n);
+  hipLaunchKernelGGL(k_adam, grid, dim3(256), 0, st, tab, a);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
+  EmbTabArgs a{};
+  a.temb = e->temb; a.We = e->p + e->off_we; a.be = e->p + e->off_be; a.W0 = e->p + e->off_w0; a.b0 = e->p + e->off_b0;
+  a.Etab = e->Etab; a.W0c = e->W0c; a.B0tab = for_sampling ? e->B0tab : nullptr;
+  a.L = e->L; a.W = e->W; a.T = e->T; a.LP = e->LP; a.WP = e->WP; a.K0 = e->K0;
+  hipLaunchKernelGGL(k_emb_tables, dim3(e->T + 1), dim3(256), 2 * e->T * sizeof(float), st, a);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+// eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
+// (its bias / K differ between training and sampling).
+int hidden_forward(sdrm_engine* e, int MP, hipStream_t st) {
+  for (int k = 1; k <= e->H; ++k) {
+    GemmArgs a{};
+    a.C = pre_buf(e, k); a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1), e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st)));
+  }
+  return SDRM_OK;
+}
+
+int upload_schedule(sdrm_engine* e, float beta1, float beta2) {
+  const int T = e->T, n = T + 1;
+  // fp32 arithmetic in the reference's op order (train_SDRM.py:300-303): linspace, affine, 1-b, log, cumsum, exp
+  std::vector<float> b(n), al(n), ab(n), sq(n), om(n);
+  const float step = 1.0f / (float)T;  // torch.linspace(0,1,T+1): start + i*step for the lower half, end - (n-1-i)*step above
+  float run = 0.f;
+  for (int i = 0; i < n; ++i) {
+    const float lin = (i < n / 2) ? (0.f + step * (float)i) : (1.f - step * (float)(n - 1 - i));
+    b[i] = (beta2 - beta1) * lin + beta1;
+    al[i] = 1.f - b[i];
+    run += std::log(al[i]);
+    ab[i] = std::exp(run);
+  }
+  ab[0] = 1.f;
+  for (int i = 0; i < n; ++i) { sq[i] = std::sqrt(ab[i]); om[i] = 1.f - ab[i]; }
+  e->h_beta = b; e->h_alpha = al; e->h_alphabar = ab;
+  HIP_TRY(e, hipMemcpy(e->sched + 0 * n, b.data(), n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->sched + 1 * n, al.data(), n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->sched + 2 * n, ab.data(), n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->sched + 3 * n, sq.data(), n * 4, hipMemcpyHostToDevice));
+  HIP_TRY(e, hipMemcpy(e->sched + 4 * n, om.data(), n * 4, hipMemcpyHostToDevice));
+  return SDRM_OK;
+}
+
+int upload_temb(sdrm_engine* e) {
+  const int T = e->T, half = T / 2;
+  std::vector<float> tab((size_t)(T + 1) * T, 0.f), freqs(half);
+  // train_SDRM.py:105-112 in fp32: exp(-ln(1e4) * k / half)
+  const float nl = -(float)std::log(10000.0);
+  for (int k = 0; k < half; ++k) freqs[k] = std::exp(nl * (float)k / (float)half);
+  for (int t = 0; t <= T; ++t)
+    for (int k = 0; k < half; ++k) {
+      const float arg = (float)t * freqs[k];
+      tab[(size_t)t * T + k] = std::cos(arg);
+      tab[(size_t)t * T + half + k] = std::sin(arg);
+    }
+  HIP_TRY(e, hipMemcpy(e->temb, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  return SDRM_OK;
+}
+
+void reverse_coeffs(const sdrm_engine* e, int i, float& c1, float& sa, float& sb) {
+  const float a = e->h_alpha[i], ab = e->h_alphabar[i], b = e->h_beta[i];
+  c1 = (1.f - a) / std::sqrt(1.f - ab);
+  sa = std::sqrt(a);
+  sb = std::sqrt(b);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char* sdrm_build_info(void) {
+  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block 128x128x16, 4 waves x (2x2 tiles of 32x32); LDS 33 KB "
+         "double-buffered; split-K slabs for wgrad";
+}
+
+const char* sdrm_last_error(const sdrm_engine* e) { return e ? e->err.c_str() : "null engine"; }
+int64_t sdrm_param_count(const sdrm_engine* e) { return e ? e->P : -1; }
+
+int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_engine** out) {
+  if (!out) return SDRM_ERR_ARG;
+  *out = nullptr;
+  if (L < 1 || L > 4096 || W < 1 || W > 4096 || T < 2 || T > 1024 || H < 0 || H > 16 || max_rows < 1 ||
+      max_rows > (1 << 22))
+    return SDRM_ERR_SHAPE;
+  sdrm_engine* e = new sdrm_engine();
+  e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
+  e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
+  e->MPmax = round_up(3 * max_rows, BM);
+  int64_t o = 0;
+  e->off_we = o; o += (int64_t)T * T;
+  e->off_be = o; o += T;
+  e->off_w0 = o; o += (int64_t)W * (L + T);
+  e->off_b0 = o; o += W;
+  e->off_a0 = o; o += 1;
+  if (H >= 1) {
+    e->off_wh = o; o += (int64_t)W * W;
+    e->off_bh = o; o += W;
+    e->off_ah = o; o += 1;
+  } else {
+    e->off_wh = e->off_bh = e->off_ah = -1;
+  }
+  e->off_wo = o; o += (int64_t)L * W;
+  e->off_bo = o; o += L;
+  e->P = o;
+  *out = e;  // handed out even on failure below so the caller can read the message and destroy
+  HIP_TRY(e, hipSetDevice(device_id));
+  const size_t MP = e->MPmax;
+  const int n = T + 1;
+  HIP_TRY(e, dalloc(&e->p, e->P)); HIP_TRY(e, dalloc(&e->m, e->P));
+  HIP_TRY(e, dalloc(&e->v, e->P)); HIP_TRY(e, dalloc(&e->g, e->P));
+  HIP_TRY(e, dalloc(&e->W0c, (size_t)e->WP * e->K0)); HIP_TRY(e, dalloc(&e->b0c, e->WP));
+  HIP_TRY(e, dalloc(&e->Whc, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
+  HIP_TRY(e, dalloc(&e->Woc, (size_t)e->LP * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
+  HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
+  HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
+  HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
+  HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
+  HIP_TRY(e, dalloc(&e->dA, MP * e->WP)); HIP_TRY(e, dalloc(&e->dB, MP * e->WP));
+  HIP_TRY(e, dalloc(&e->X, MP * e->LP));
+  HIP_TRY(e, dalloc(&e->slab0, (size_t)S_MAX * e->WP * e->K0)); HIP_TRY(e, dalloc(&e->db0s, (size_t)S_MAX * e->WP));
+  HIP_TRY(e, dalloc(&e->slabO, (size_t)S_MAX * e->LP * e->WP)); HIP_TRY(e, dalloc(&e->dbOs, (size_t)S_MAX * e->LP));
+  if (H >= 1) {
+    HIP_TRY(e, dalloc(&e->slabH, (size_t)H * S_MAX * e->WP * e->WP));
+    HIP_TRY(e, dalloc(&e->dbHs, (size_t)H * S_MAX * e->WP));
+  }
+  e->alpha_part_stride = (int)((MP / BM) * ((e->WP + BN - 1) / BN));
+  HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
+  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
+  HIP_TRY(e, dalloc(&e->dC0, (size_t)n * W)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
+  HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows));
+  int rc = upload_schedule(e, 1e-4f, 0.02f);
+  if (rc) return rc;
+  rc = upload_temb(e);
+  if (rc) return rc;
+  HIP_TRY(e, hipDeviceSynchronize());
+  return SDRM_OK;
+}
+
+int sdrm_destroy(sdrm_engine* e) {
+  if (!e) return SDRM_ERR_ARG;
+  (void)hipSetDevice(e->device);
+  void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
+                  e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->dB, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  delete e;
+  return SDRM_OK;
+}
+
+int sdrm_set_schedule(sdrm_engine* e, float beta1, float beta2) {
+  if (!e) return SDRM_ERR_ARG;
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipDeviceSynchronize());
+  return upload_schedule(e, beta1, beta2);
+}
+
+int sdrm_get_schedule(const sdrm_engine* e, float* b, float* a, float* ab) {
+  if (!e || !b || !a || !ab) return SDRM_ERR_ARG;
+  const size_t n = (size_t)e->T + 1;
+  std::memcpy(b, e->h_beta.data(), n * 4);
+  std::memcpy(a, e->h_alpha.data(), n * 4);
+  std::memcpy(ab, e->h_alphabar.data(), n * 4);
+  return SDRM_OK;
+}
+
+int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream) {
+  if (!e || !flat) return fail(e, SDRM_ERR_ARG, "sdrm_set_params: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(e, hipMemcpyAsync(e->p, flat, e->P * 4, hipMemcpyDeviceToDevice, st));
+  return launch_adam(e, nullptr, 0.f, 0, st);  // re-pack only
+}
+
+int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream) {
+  if (!e || !flat) return SDRM_ERR_ARG;
+  sdrm_engine* me = const_cast<sdrm_engine*>(e);
+  HIP_TRY(me, hipMemcpyAsync(flat, e->p, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SDRM_OK;
+}
+
+int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream) {
+  if (!e || !flat) return SDRM_ERR_ARG;
+  sdrm_engine* me = const_cast<sdrm_engine*>(e);
+  HIP_TRY(me, hipMemcpyAsync(flat, e->g, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SDRM_OK;
+}
+
+int sdrm_get_adam_state(const sdrm_engine* e, float* m, float* v, int64_t* step_host, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  sdrm_engine* me = const_cast<sdrm_engine*>(e);
+  if (m) HIP_TRY(me, hipMemcpyAsync(m, e->m, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (v) HIP_TRY(me, hipMemcpyAsync(v, e->v, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (step_host) *step_host = e->adam_t;
+  return SDRM_OK;
+}
+
+int sdrm_set_adam_state(sdrm_engine* e, const float* m, const float* v, int64_t step, void* stream) {
+  if (!e || step < 0) return fail(e, SDRM_ERR_ARG, "sdrm_set_adam_state: bad argument");
+  if (m) HIP_TRY(e, hipMemcpyAsync(e->m, m, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (v) HIP_TRY(e, hipMemcpyAsync(e->v, v, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  e->adam_t = step;
+  return SDRM_OK;
+}
+
+int sdrm_adam_reset(sdrm_engine* e, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  HIP_TRY(e, hipMemsetAsync(e->m, 0, e->P * 4, (hipStream_t)stream));
+  HIP_TRY(e, hipMemsetAsync(e->v, 0, e->P * 4, (hipStream_t)stream));
+  e->adam_t = 0;
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd,
+                       uint64_t seed, uint64_t step, float nd, double* sums, void* stream) {
+  if (!e || !x0) return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: null pointer");
+  if (B < 1 || B > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_train_forward: B outside [1, max_rows]");
+  if (mode == SDRM_RNG_EXPLICIT && (!rnd || !rnd->noise || !rnd->t || !rnd->keep))
+    return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: EXPLICIT mode needs noise, t and keep");
+  if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
+  hipStream_t st = (hipStream_t)stream;
+  const int MP = round_up(3 * B, BM), n = e->T + 1;
+  e->fwd_done = false;
+
+  PrepTrainArgs pa{};
+  pa.x0 = x0;
+  if (mode == SDRM_RNG_EXPLICIT) { pa.noise = rnd->noise; pa.t = rnd->t; pa.keep = rnd->keep; }
+  pa.sqrt_ab = e->sched + 3 * n; pa.one_minus_ab = e->sched + 4 * n;
+  pa.U = e->U; pa.tdev = e->tdev;
+  pa.B = B; pa.L = e->L; pa.LP = e->LP; pa.K0 = e->K0; pa.T = e->T; pa.MP = MP;
+  pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
+  pa.row0 = row0; pa.nd = nd;
+  {
+    dim3 grid((e->K0 / 2 + 255) / 256, B + (MP - 3 * B));
+    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 0, st, pa);
+    HIP_TRY(e, hipGetLastError());
+  }
+  int rc = emb_tables(e, false, st);
+  if (rc) return rc;
+  {
+    GemmArgs a{};
+    a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st)));
+  }
+  rc = hidden_forward(e, MP, st);
+  if (rc) return rc;
+  {
+    GemmArgs a{};
+    a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+    a.rows_valid = MP; a.cols_valid = e->LP;
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+  }
+  LossArgs la{};
+  la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
+  hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(256), 0, st, la);
+  HIP_TRY(e, hipGetLastError());
+  hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
+                     (double)B * (double)e->L, sums ? sums : e->sums);
+  HIP_TRY(e, hipGetLastError());
+  e->cur_B = B; e->cur_MP = MP; e->cur_x0 = x0; e->fwd_done = true;
+  return SDRM_OK;
+}
+
+int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = e->cur_B, MP = e->cur_MP, H = e->H;
+  SeedArgs sa{};
+  sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
+  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
+  {
+    dim3 grid((e->LP + 255) / 256, B + (MP - 3 * B));
+    hipLaunchKernelGGL(k_loss_seed, grid, dim3(256), 0, st, sa);
+    HIP_TRY(e, hipGetLastError());
+  }
+  int S0, SH, SO, kc0, kcH, kcO;
+  pick_splits(MP, e->WP, e->K0, S0, kc0);
+  pick_splits(MP, e->WP, e->WP, SH, kcH);
+  pick_splits(MP, e->LP, e->WP, SO, kcO);
+  const int dgrad_blocks = (MP / BM) * ((e->WP + BN - 1) / BN);
+  // output layer
+  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, kcO,
+                                   e->slabO, e->dbOs, st)));
+  float* dcur = e->dA;
+  float* dnext = e->dB;
+  HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->Woc, e->WP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
+                        e->alpha_part + (size_t)H * e->alpha_part_stride, st));
+  // shared hidden layer, applications H..1
+  for (int k = H; k >= 1; --k) {
+    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dcur, e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
+                                     kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
+                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st)));
+    HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
+                          slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st));
+    float* tmp = dcur; dcur = dnext; dnext = tmp;
+  }
+  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
+  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st)));
+  EmbBwdArgs ea{};
+  ea.slab0 = e->slab0; ea.slab_stride = (size_t)e->WP * e->K0; ea.S = S0;
+  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dC0 = e->dC0; ea.dE = e->dE; ea.g = e->g;
+  ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
+  ea.L = e->L; ea.W = e->W; ea.T = e->T; ea.LP = e->LP; ea.K0 = e->K0;
+  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(256), e->W * sizeof(float), st, ea);
+  HIP_TRY(e, hipGetLastError());
+  {
+    const int items = e->W * e->T + e->T * e->T + e->T;
+    hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
+    HIP_TRY(e, hipGetLastError());
+  }
+  JobTable tab;
+  build_jobs(e, tab, S0, SH, SO, dgrad_blocks);
+  hipLaunchKernelGGL(k_grad_finalize, dim3(128, tab.n), dim3(256), 0, st, tab, e->g);
+  HIP_TRY(e, hipGetLastError());
+  if (grad && grad != e->g) HIP_TRY(e, hipMemcpyAsync(grad, e->g, e->P * 4, hipMemcpyDeviceToDevice, st));
+  e->last_S = S0; e->last_dgrad_blocks = dgrad_blocks;
+  return SDRM_OK;
+}
+
+int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  e->adam_t += 1;
+  return launch_adam(e, grad, lr, 1, (hipStream_t)stream);
+}
+
+int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,
+                    uint64_t seed, uint64_t step, float nd, float* loss, void* stream) {
+  int rc = sdrm_train_forward(e, x0, B, 0, mode, rnd, seed, step, nd, nullptr, stream);
+  if (rc) return rc;
+  rc = sdrm_train_backward(e, nullptr, nullptr, loss, stream);
+  if (rc) return rc;
+  return sdrm_adam_step(e, nullptr, lr, stream);
+}
+
+int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
+  if (!e || !psq) return SDRM_ERR_ARG;
+  sdrm_engine* me = const_cast<sdrm_engine*>(e);
+  if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_train_outputs: no forward yet");
+  hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
+                     e->LP, psq);
+  HIP_TRY(me, hipGetLastError());
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_uniform, int n, int mode,
+                        const uint8_t* keep, uint64_t seed, uint64_t step, int64_t row0, float* out, int ldout,
+                        int cols_valid, hipStream_t st) {
+  const int MP = round_up(n, BM);
+  PrepFwdArgs pa{};
+  pa.x = x; pa.t = t; pa.t_uniform = t_uniform; pa.keep = keep; pa.U = e->U;
+  pa.n = n; pa.L = e->L; pa.LP = e->LP; pa.K0 = e->K0; pa.T = e->T; pa.MP = MP;
+  pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
+  pa.row0 = row0;
+  dim3 grid((e->K0 / 2 + 255) / 256, MP);
+  hipLaunchKernelGGL(k_prep_forward, grid, dim3(256), 0, st, pa);
+  HIP_TRY(e, hipGetLastError());
+  int rc = emb_tables(e, false, st);
+  if (rc) return rc;
+  {
+    GemmArgs a{};
+    a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st)));
+  }
+  rc = hidden_forward(e, MP, st);
+  if (rc) return rc;
+  GemmArgs a{};
+  a.C = out; a.ldc = ldout; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+  a.rows_valid = n; a.cols_valid = cols_valid;
+  HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+  return SDRM_OK;
+}
+
+int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mode, const uint8_t* keep, uint64_t seed,
+                 uint64_t step, int64_t row0, float* out, void* stream) {
+  if (!e || !x || !t || !out) return fail(e, SDRM_ERR_ARG, "sdrm_forward: null pointer");
+  if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_forward: n outside [1, 3*max_rows]");
+  if (mode == SDRM_RNG_EXPLICIT && !keep) return fail(e, SDRM_ERR_ARG, "sdrm_forward: EXPLICIT mode needs keep");
+  e->fwd_done = false;
+  return forward_rows(e, x, t, 0, n, mode, keep, seed, step, row0, out, e->L, e->L, (hipStream_t)stream);
+}
+
+int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, const uint8_t* keep, void* stream) {
+  if (!e || !x || !keep) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: null pointer");
+  if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_reverse_step: n outside [1, 3*max_rows]");
+  if (i < 1 || i > e->T) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: step outside [1, T]");
+  hipStream_t st = (hipStream_t)stream;
+  e->fwd_done = false;
+  int rc = forward_rows(e, x, nullptr, i, n, SDRM_RNG_EXPLICIT, keep, 0, 0, 0, e->Y, e->LP, e->LP, st);
+  if (rc) return rc;
+  float c1, sa, sb;
+  reverse_coeffs(e, i, c1, sa, sb);
+  hipLaunchKernelGGL(k_reverse_apply, dim3(256), dim3(256), 0, st, x, (const float*)e->Y, e->LP, z, n, e->L, c1, sa, sb);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const float* noise, int n, float* out,
+                       void* stream) {
+  if (!e || !x || !t || !noise || !out || n < 1) return fail(e, SDRM_ERR_ARG, "sdrm_perturb_input: bad argument");
+  const int nn = e->T + 1;
+  hipLaunchKernelGGL(k_perturb, dim3(256), dim3(256), 0, (hipStream_t)stream, x, t, noise,
+                     (const float*)(e->sched + 3 * nn), (const float*)(e->sched + 4 * nn), n, e->L, e->T, out);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+int sdrm_sample(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
+                const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0, float* out,
+                int64_t* Tj_out, void* stream) {
+  if (!e || !out) return fail(e, SDRM_ERR_ARG, "sdrm_sample: null pointer");
+  if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: n outside [1, 3*max_rows]");
+  if (mode == SDRM_RNG_EXPLICIT && (!xT || !z || !keep || (multires && !Tj)))
+    return fail(e, SDRM_ERR_ARG, "sdrm_sample: EXPLICIT mode needs xT, z, keep (and Tj for multi-resolution)");
+  if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
+  hipStream_t st = (hipStream_t)stream;
+  const int T = e->T, L = e->L, MP = round_up(n, BM);
+  e->fwd_done = false;
+  int rc = emb_tables(e, true, st);
+  if (rc) return rc;
+  // PHILOX multi-resolution draws Tj in [1, T-1] (np.random.randint(1, T), :42), so step T is never active
+  const int i_start = (multires && mode == SDRM_RNG_PHILOX && T > 1) ? T - 1 : T;
+  const size_t nL = (size_t)n * L;
+  SampleInitArgs ia{};
+  ia.xT = xT; ia.keep = keep ? keep + (size_t)i_start * nL : nullptr; ia.Tj_in = Tj;
+  ia.Tj_dev = multires ? e->Tj_dev : nullptr; ia.Tj_out = multires ? Tj_out : nullptr;
+  ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T; ia.i_start = i_start;
+  ia.mode = mode; ia.multires = multires; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
+  ia.call_id = (uint32_t)call_id; ia.row0 = row0;
+  if (multires && n > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: multi-resolution n > max_rows");
+  {
+    dim3 grid((e->LP / 2 + 255) / 256, MP);
+    hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
+    HIP_TRY(e, hipGetLastError());
+  }
+  for (int i = i_start; i >= 1; --i) {
+    {
+      GemmArgs a{};
+      a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
+      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st)));
+    }
+    rc = hidden_forward(e, MP, st);
+    if (rc) return rc;
+    GemmArgs a{};
+    a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+    a.ldc = e->LP; a.rows_valid = n; a.Lreal = L;
+    a.X = e->X; a.Unext = e->U; a.ldu = e->K0;
+    a.Z = (mode == SDRM_RNG_EXPLICIT && i > 1) ? z + (size_t)i * nL : nullptr;
+    a.keep_next = (mode == SDRM_RNG_EXPLICIT && i > 1) ? keep + (size_t)(i - 1) * nL : nullptr;
+    a.Tj = multires ? e->Tj_dev : nullptr;
+    a.step_i = i; a.nd = nd;
+    reverse_coeffs(e, i, a.c1, a.sqrt_alpha, a.sqrt_beta);
+    a.rng_mode = mode; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.call_id = (uint32_t)call_id;
+    a.row0 = row0;
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REVERSE>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+  }
+  hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, st, (const float*)e->X, e->LP, out, n, L);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
+  if (!A || !B || !C) return SDRM_ERR_ARG;
+  if (M % 32 || N % 32 || K % 32) return SDRM_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.C = C; a.ldc = N; a.K = K; a.kchunk = K;
+  hipError_t rc;
+  if (variant == 0) {
+    if (M % BM) return SDRM_ERR_SHAPE;
+    a.A = A; a.lda = K; a.limA = M; a.B = B; a.ldb = K; a.limB = N;
+    rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+  } else if (variant == 1) {
+    if (M % BM) return SDRM_ERR_SHAPE;
+    a.A = A; a.lda = K; a.limA = M; a.B = B; a.ldb = N; a.limB = N;
+    rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+  } else if (variant == 2) {
+    if (K % BM) return SDRM_ERR_SHAPE;
+    a.A = A; a.lda = M; a.limA = M; a.B = B; a.ldb = N; a.limB = N;
+    rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+  } else {
+    return SDRM_ERR_ARG;
+  }
+  return rc == hipSuccess ? SDRM_OK : SDRM_ERR_HIP;
+}
+
+}  // extern "C"

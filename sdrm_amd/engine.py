@@ -1,0 +1,231 @@
+"""Python handle over the C ABI: owns one `sdrm_engine` and passes torch device pointers through.
+
+torch is used only for device memory and streams (plumbing); every numeric step runs in
+libsdrm_hip.so.  Reference lines are into /root/reference/train_SDRM.py."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, synth
+
+
+class SdrmError(RuntimeError):
+    pass
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """eps-predictor SDRM(N_ITEMS=L, EMB_DIM=T, LATENT_DIM=W, n_hidden_layers=H) (:86-95) with its
+    Adam state (:309) and DDPM schedule (:296-303) resident on one MI355X."""
+
+    def __init__(self, L, W, T, H, max_rows, device=None):
+        if not torch.cuda.is_available():
+            raise SdrmError("sdrm_amd needs a ROCm device: no GPU is visible and there is no CPU fallback")
+        self.lib = _lib.load()
+        self.L, self.W, self.T, self.H, self.max_rows = int(L), int(W), int(T), int(H), int(max_rows)
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self._h = C.c_void_p()
+        rc = self.lib.sdrm_create(self.L, self.W, self.T, self.H, self.max_rows, self.device.index, C.byref(self._h))
+        if rc != 0:
+            msg = self.lib.sdrm_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self.lib.sdrm_destroy(self._h)
+                self._h = C.c_void_p()
+            raise SdrmError(f"sdrm_create failed: {_lib.STATUS.get(rc, rc)} {msg}")
+        self.P = int(self.lib.sdrm_param_count(self._h))
+        assert self.P == synth.param_count(self.L, self.W, self.T, self.H)
+        self._sums = torch.zeros(8, dtype=torch.float64, device=self.device)
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._keepalive = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.sdrm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SdrmError(f"{what}: {_lib.STATUS.get(rc, rc)}: {self.lib.sdrm_last_error(self._h).decode()}")
+
+    def _dev(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=dtype)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ parameters
+    def set_params(self, flat):
+        flat = self._dev(flat, torch.float32).reshape(-1)
+        if flat.numel() != self.P:
+            raise SdrmError(f"set_params: expected {self.P} floats, got {flat.numel()}")
+        self._check(self.lib.sdrm_set_params(self._h, _ptr(flat), _stream()), "sdrm_set_params")
+        self._keepalive = flat
+
+    def _flat_out(self, fn, name):
+        out = torch.empty(self.P, dtype=torch.float32, device=self.device)
+        self._check(fn(self._h, _ptr(out), _stream()), name)
+        return out
+
+    def get_params(self):
+        return self._flat_out(self.lib.sdrm_get_params, "sdrm_get_params")
+
+    def get_grads(self):
+        return self._flat_out(self.lib.sdrm_get_grads, "sdrm_get_grads")
+
+    def get_adam_state(self):
+        m = torch.empty(self.P, dtype=torch.float32, device=self.device)
+        v = torch.empty(self.P, dtype=torch.float32, device=self.device)
+        step = C.c_int64()
+        self._check(self.lib.sdrm_get_adam_state(self._h, _ptr(m), _ptr(v), C.byref(step), _stream()), "sdrm_get_adam_state")
+        return m, v, int(step.value)
+
+    def set_adam_state(self, m, v, step):
+        m, v = self._dev(m, torch.float32), self._dev(v, torch.float32)
+        self._check(self.lib.sdrm_set_adam_state(self._h, _ptr(m), _ptr(v), int(step), _stream()), "sdrm_set_adam_state")
+        self._keepalive = (m, v)
+
+    def adam_reset(self):
+        self._check(self.lib.sdrm_adam_reset(self._h, _stream()), "sdrm_adam_reset")
+
+    def set_schedule(self, beta1=1e-4, beta2=0.02):
+        self._check(self.lib.sdrm_set_schedule(self._h, beta1, beta2), "sdrm_set_schedule")
+
+    def get_schedule(self):
+        n = self.T + 1
+        b, a, ab = (np.empty(n, np.float32) for _ in range(3))
+        self._check(self.lib.sdrm_get_schedule(self._h, b.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p),
+                                               ab.ctypes.data_as(C.c_void_p)), "sdrm_get_schedule")
+        return b, a, ab
+
+    # ------------------------------------------------------------------ training
+    def _randoms(self, noise, t, keep, B):
+        noise = self._dev(noise, torch.float32)
+        t = self._dev(t, torch.int64)
+        keep = self._dev(keep, torch.uint8)
+        if tuple(noise.shape) != (B, self.L) or tuple(t.shape) != (B,) or tuple(keep.shape) != (3, B, self.L):
+            raise SdrmError("explicit randoms: expected noise [B,L], t [B], keep [3,B,L]")
+        self._keepalive = (noise, t, keep)
+        return _lib.TrainRandoms(noise.data_ptr(), t.data_ptr(), keep.data_ptr())
+
+    def train_forward(self, x0, noise=None, t=None, keep=None, seed=0, step=0, nd=1.0, row0=0, sums=None):
+        """Phase 1 (:326-333 up to the loss sums).  Explicit randoms if `noise` is given, else Philox."""
+        x0 = self._dev(x0, torch.float32)
+        B = x0.shape[0]
+        if x0.dim() != 2 or x0.shape[1] != self.L:
+            raise SdrmError(f"train_forward: x0 must be [B,{self.L}]")
+        self._x0 = x0
+        sums = self._sums if sums is None else sums
+        if noise is not None:
+            rnd = self._randoms(noise, t, keep, B)
+            rc = self.lib.sdrm_train_forward(self._h, _ptr(x0), B, int(row0), _lib.RNG_EXPLICIT, C.byref(rnd), 0, 0,
+                                             float(nd), _ptr(sums), _stream())
+        else:
+            rc = self.lib.sdrm_train_forward(self._h, _ptr(x0), B, int(row0), _lib.RNG_PHILOX, None, int(seed),
+                                             int(step), float(nd), _ptr(sums), _stream())
+        self._check(rc, "sdrm_train_forward")
+        return sums
+
+    def train_backward(self, sums=None, grad=None):
+        """Phase 2: seeds from the (global) sums, backward, flat gradient.  Returns the device loss scalar."""
+        sums = self._sums if sums is None else sums
+        self._check(self.lib.sdrm_train_backward(self._h, _ptr(sums), _ptr(grad), _ptr(self._loss), _stream()),
+                    "sdrm_train_backward")
+        return self._loss
+
+    def adam_step(self, lr, grad=None):
+        """Phase 3: coupled-L2 Adam (:309,:337) at the caller's per-epoch lr (:316)."""
+        self._check(self.lib.sdrm_adam_step(self._h, _ptr(grad), float(lr), _stream()), "sdrm_adam_step")
+
+    def train_step(self, x0, lr, noise=None, t=None, keep=None, seed=0, step=0, nd=1.0):
+        """One whole step (:326-337) on this GPU; returns the device loss scalar (no host sync, Q14)."""
+        x0 = self._dev(x0, torch.float32)
+        B = x0.shape[0]
+        if x0.dim() != 2 or x0.shape[1] != self.L:
+            raise SdrmError(f"train_step: x0 must be [B,{self.L}]")
+        self._x0 = x0
+        if noise is not None:
+            rnd = self._randoms(noise, t, keep, B)
+            rc = self.lib.sdrm_train_step(self._h, _ptr(x0), B, float(lr), _lib.RNG_EXPLICIT, C.byref(rnd), 0, 0,
+                                          float(nd), _ptr(self._loss), _stream())
+        else:
+            rc = self.lib.sdrm_train_step(self._h, _ptr(x0), B, float(lr), _lib.RNG_PHILOX, None, int(seed), int(step),
+                                          float(nd), _ptr(self._loss), _stream())
+        self._check(rc, "sdrm_train_step")
+        return self._loss
+
+    def train_outputs(self, B):
+        out = torch.empty(3, B, self.L, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_get_train_outputs(self._h, _ptr(out), _stream()), "sdrm_get_train_outputs")
+        return out
+
+    # ------------------------------------------------------------------ inference
+    def forward(self, x, t, keep=None, seed=0, step=0, row0=0):
+        """SDRM.forward(x, t) (:97-103); dropout is always on (Q2)."""
+        x = self._dev(x, torch.float32)
+        t = self._dev(t, torch.int64)
+        n = x.shape[0]
+        out = torch.empty(n, self.L, dtype=torch.float32, device=self.device)
+        if keep is not None:
+            keep = self._dev(keep, torch.uint8)
+            rc = self.lib.sdrm_forward(self._h, _ptr(x), _ptr(t), n, _lib.RNG_EXPLICIT, _ptr(keep), 0, 0, 0, _ptr(out),
+                                       _stream())
+        else:
+            rc = self.lib.sdrm_forward(self._h, _ptr(x), _ptr(t), n, _lib.RNG_PHILOX, None, int(seed), int(step),
+                                       int(row0), _ptr(out), _stream())
+        self._check(rc, "sdrm_forward")
+        self._keepalive = (x, t, keep)
+        return out
+
+    def sample(self, n, nd=1.0, multires=False, xT=None, z=None, keep=None, Tj=None, seed=0, call_id=0, row0=0,
+               return_Tj=False):
+        """Latent part of sample_ddpm (:37-59): returns x_0 latents [n,L] (caller applies vae.decode)."""
+        out = torch.empty(n, self.L, dtype=torch.float32, device=self.device)
+        tj_out = torch.zeros(n, dtype=torch.int64, device=self.device) if (multires and return_Tj) else None
+        if xT is not None:
+            xT, z, keep = self._dev(xT, torch.float32), self._dev(z, torch.float32), self._dev(keep, torch.uint8)
+            Tj = None if Tj is None else self._dev(Tj, torch.int64)
+            if tuple(z.shape) != (self.T + 1, n, self.L) or tuple(keep.shape) != (self.T + 1, n, self.L):
+                raise SdrmError("sample: z and keep must be [T+1,n,L]")
+            rc = self.lib.sdrm_sample(self._h, n, float(nd), int(bool(multires)), _lib.RNG_EXPLICIT, _ptr(xT), _ptr(z),
+                                      _ptr(keep), _ptr(Tj), 0, 0, 0, _ptr(out), _ptr(tj_out), _stream())
+        else:
+            rc = self.lib.sdrm_sample(self._h, n, float(nd), int(bool(multires)), _lib.RNG_PHILOX, None, None, None,
+                                      None, int(seed), int(call_id), int(row0), _ptr(out), _ptr(tj_out), _stream())
+        self._check(rc, "sdrm_sample")
+        self._keepalive = (xT, z, keep, Tj)
+        return (out, tj_out) if return_Tj else out
+
+    def reverse_step(self, x, i, z, keep):
+        x = self._dev(x, torch.float32).clone()
+        z = None if z is None else self._dev(z, torch.float32)
+        keep = self._dev(keep, torch.uint8)
+        self._check(self.lib.sdrm_reverse_step(self._h, _ptr(x), x.shape[0], int(i), _ptr(z), _ptr(keep), _stream()),
+                    "sdrm_reverse_step")
+        self._keepalive = (z, keep)
+        return x
+
+    def perturb_input(self, x, t, noise):
+        x, t, noise = self._dev(x, torch.float32), self._dev(t, torch.int64), self._dev(noise, torch.float32)
+        out = torch.empty_like(x)
+        self._check(self.lib.sdrm_perturb_input(self._h, _ptr(x), _ptr(t), _ptr(noise), x.shape[0], _ptr(out), _stream()),
+                    "sdrm_perturb_input")
+        return out
