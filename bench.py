@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising-steps/sec (train + sample) on ML-1M-shaped latents.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3]; SURVEY.md §8d "C3/C4"): eps-net L=W=340, T=78, H=1
+(README ML-1M/MLP hyper-parameters), synthetic N(0,1) latents, global train batch B=8192 users,
+15 epochs x 1 batch, then full-resolution reverse sampling of 5429 users for 78 steps.  One "step"
+is one pass of the hot path over one batch: either a train step (q_sample + 3 eps-net forwards +
+score-matching loss + backward + Adam; train_SDRM.py:326-337) or a reverse-sampling step (eps-net
+forward + denoise_add_noise; train_SDRM.py:56-59).  The K timed steps walk the job's own 15:78
+train:sample mix cyclically.  Randomness is the engine's Philox mode.  N>1: the batch and the sampled
+users are sharded over ranks (strong scaling: the job is fixed), RCCL all-reduce of 5 loss scalars and
+of the flat gradient per train step, no communication while sampling.
+
+Prints ONE JSON line on rank 0."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from sdrm_amd import synth  # noqa: E402
+
+WL = dict(name="ML-1M/MLP shaped synthetic latents (C3/C4)", L=340, W=340, T=78, H=1, B=8192, n_sample=5429,
+          epochs=15, batches_per_epoch=1, lr=9.8e-5, nd=1.0)
+PEAK_FP32_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+
+
+def is_train(k: int, n_train: int, cycle: int) -> bool:
+    """Bresenham spread of n_train train steps over a cycle of `cycle` steps."""
+    j = k % cycle
+    return ((j + 1) * n_train) // cycle > (j * n_train) // cycle
+
+
+def train_flops(B, L, T, H):      # 6*B*(2T^2 + 3TL + (3H+5)L^2)
+    return 6.0 * B * (2 * T * T + 3 * T * L + (3 * H + 5) * L * L)
+
+
+def sample_flops(n, L, T, H):     # n * 2*(T^2 + T*L + (H+2)*L^2)
+    return 2.0 * n * (T * T + T * L + (H + 2) * L * L)
+
+
+class Job:
+    """Walks the job's step mix on one rank."""
+
+    def __init__(self, engine, trainer, x0_local, row0, n_local, srow0, wl, seed=1234):
+        self.e, self.tr, self.x0, self.row0 = engine, trainer, x0_local, row0
+        self.n_local, self.srow0, self.wl, self.seed = n_local, srow0, wl, seed
+        self.n_train = wl["epochs"] * wl["batches_per_epoch"]
+        self.cycle = self.n_train + wl["T"]
+        self.k = 0
+        self.train_count = 0
+        self.sampling = False
+        self.call_id = 0
+
+    def lr(self):
+        ep = (self.train_count // self.wl["batches_per_epoch"]) % self.wl["epochs"]
+        return self.wl["lr"] * (1 - ep / self.wl["epochs"])      # train_SDRM.py:316
+
+    def step(self):
+        wl = self.wl
+        if is_train(self.k, self.n_train, self.cycle):
+            self.tr.train_step(self.x0, self.lr(), row0=self.row0, step=self.train_count, seed=self.seed, nd=wl["nd"])
+            self.train_count += 1
+            kind = "train"
+        else:
+            if not self.sampling:
+                self.e.sample_begin(self.n_local, nd=wl["nd"], seed=self.seed, call_id=self.call_id, row0=self.srow0)
+                self.sampling = True
+                self.call_id += 1
+            if self.e.sample_steps(1) == 0:
+                self.e.sample_end()
+                self.sampling = False
+            kind = "sample"
+        self.k += 1
+        return kind
+
+
+def cpu_baseline(wl, seconds_budget=25.0):
+    """The CPU oracle (torch CPU ops, all host cores) on the same step mix: one whole job cycle if it
+    fits the budget, else a proportional prefix."""
+    from oracle import sdrm_oracle as orc
+    L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    o = orc.Oracle(L, W, T, H, synth.init_params(L, W, T, H, seed=1))
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0))
+    g = torch.Generator().manual_seed(0)
+    n_train = wl["epochs"] * wl["batches_per_epoch"]
+    cycle = n_train + T
+    x = torch.randn(n, L, generator=g)
+    done = {"train": 0, "sample": 0}
+    i = T
+    t0 = time.perf_counter()
+    for k in range(cycle):
+        if is_train(k, n_train, cycle):
+            eps = torch.randn(B, L, generator=g) * wl["nd"]
+            t = torch.randint(1, T + 1, (B,), generator=g)
+            keeps = [(torch.rand(B, L, generator=g) < 0.5).float() for _ in range(3)]
+            o.train_step(x0, eps, t, keeps, wl["lr"])
+            done["train"] += 1
+        else:
+            keep = (torch.rand(n, L, generator=g) < 0.5).float()
+            z = torch.randn(n, L, generator=g) * wl["nd"] if i > 1 else torch.zeros(n, L)
+            eps_hat = o.forward(x, torch.full((n,), i, dtype=torch.int64), keep)
+            x = orc.reverse_update(x, eps_hat, z, i, o.beta, o.alpha, o.alphabar)
+            i = i - 1 if i > 1 else T
+            done["sample"] += 1
+        if time.perf_counter() - t0 > seconds_budget and done["train"] >= 2 and done["sample"] >= 10:
+            break
+    dt = time.perf_counter() - t0
+    steps = done["train"] + done["sample"]
+    return {"value": steps / dt, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{done['train']} train steps (B={B}) + {done['sample']} reverse-sampling steps (n={n}) of the "
+                      f"same 15:78 mix, oracle/sdrm_oracle.py on torch CPU ops, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=186)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from sdrm_amd.engine import Engine
+    from sdrm_amd.parallel import ShardedTrainer, shard_rows
+
+    wl = WL
+    L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
+    row0, rows = shard_rows(B, rank, world)
+    srow0, n_local = shard_rows(n, rank, world)
+    eng = Engine(L, W, T, H, max_rows=max(rows, n_local))
+    eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)[row0:row0 + rows]).cuda()
+    trainer = ShardedTrainer(eng, rank, world)
+    job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    t0 = time.perf_counter()
+    kinds = {"train": 0, "sample": 0}
+    for _ in range(args.steps):
+        kinds[job.step()] += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.cpu())
+
+    # ---- second, untimed-for-throughput pass of the same K steps with HIP events around every GEMM launch
+    eng.profile_begin(capacity=args.steps * 16)
+    for _ in range(args.steps):
+        job.step()
+    prof = eng.profile_end()
+
+    # ---- separate train-only / sample-only rates (extra information, not `value`)
+    def rate(fn, reps):
+        barrier()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return reps / (time.perf_counter() - t)
+
+    while eng.sample_steps(1) != 0:   # drain a sampling call left open by the cyclic walk
+        pass
+    try:
+        eng.sample_end()
+    except Exception:
+        pass
+    job.sampling = False
+    train_rate = rate(lambda: trainer.train_step(x0, wl["lr"], row0=row0, step=7, seed=99, nd=wl["nd"]), 20)
+    eng.sample_begin(n_local, nd=wl["nd"], seed=5, call_id=777, row0=srow0)
+    sample_rate = rate(lambda: eng.sample_steps(1), 60)
+
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else None
+        roof = None
+        if dom:
+            name, (ms, launches, flops) = dom
+            achieved = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(ms * 1e3 / launches, 2), "launches": launches,
+                    "algorithmic_flops_per_launch": flops / launches,
+                    "all_kernels": {k: {"ms": round(v[0], 3), "launches": v[1],
+                                        "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 2)} for k, v in prof.items()}}
+        n_train = wl["epochs"] * wl["batches_per_epoch"]
+        job_flops = (kinds["train"] * train_flops(B, L, T, H) + kinds["sample"] * sample_flops(n, L, T, H))
+        out = {
+            "metric": "denoising-steps/sec (train+sample) on ML-1M latents", "value": round(args.steps / dt, 2),
+            "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "latent": L, "width": W, "timesteps": T, "hidden_layers": H,
+                       "global_batch": B, "n_sample": n, "step_mix": f"{n_train} train : {T} sample per job cycle",
+                       "timed_train_steps": kinds["train"], "timed_sample_steps": kinds["sample"],
+                       "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}"},
+            "whole_job_tflops": round(job_flops / dt / 1e12, 2),
+            "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+            out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

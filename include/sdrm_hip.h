@@ -136,6 +136,16 @@ int sdrm_sample(sdrm_engine* e, int n, float noise_divider, int multires, int mo
                 const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,
                 int64_t row0, float* out, int64_t* Tj_out, void* stream);
 
+/* The same loop in resumable form (sdrm_sample == begin + steps(all) + end).  The EXPLICIT-mode
+ * pointers must stay valid until sdrm_sample_end.  sdrm_sample_steps runs at most `count` reverse
+ * steps; sdrm_sample_remaining returns the next step index i (0 = loop finished). */
+int sdrm_sample_begin(sdrm_engine* e, int n, float noise_divider, int multires, int mode, const float* xT,
+                      const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,
+                      int64_t row0, int64_t* Tj_out, void* stream);
+int sdrm_sample_steps(sdrm_engine* e, int count, void* stream);
+int sdrm_sample_remaining(const sdrm_engine* e);
+int sdrm_sample_end(sdrm_engine* e, float* out, void* stream);
+
 /* One reverse step on caller-owned state, for callers that drive the loop themselves:
  * x <- denoise_add_noise(x, i, f(x, i), z) (train_SDRM.py:56-59).  z may be NULL (= 0, the i==1 case). */
 int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, const uint8_t* keep, void* stream);
@@ -144,7 +154,24 @@ int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, co
 int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const float* noise, int n, float* out,
                        void* stream);
 
+/* Pre-activations of eps-net layer `layer` (0..H) from the last sdrm_train_forward, as [3,B,W]
+ * (pass order P,S,Q).  Parity tests use their signs to evaluate the oracle with the same PReLU
+ * derivative choice at pre-activations that are zero within fp32 rounding (DESIGN.md "kink flips"). */
+int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream);
+
 /* ---- introspection for bench.py / profiling ---------------------------------------------------- */
+/* Per-kernel timing with HIP events recorded on the launch stream around every GEMM launch.
+ * sdrm_profile_begin enables it (capacity = max launches recorded), sdrm_profile_end synchronises the
+ * stream and aggregates per kernel class; sdrm_profile_get returns, for class `cls`
+ * (0..sdrm_profile_classes()-1), the summed duration [ms], the launch count and the summed
+ * ALGORITHMIC flops (2*rows*N*K on the unpadded dims).  Adds two event records per launch, so it is
+ * used in a separate pass, never inside the throughput-timed region. */
+int sdrm_profile_begin(sdrm_engine* e, int capacity);
+int sdrm_profile_end(sdrm_engine* e, void* stream);
+int sdrm_profile_classes(void);
+const char* sdrm_profile_name(int cls);
+int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* launches, double* flops);
+
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
 /* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),

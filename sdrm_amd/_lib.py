@@ -43,8 +43,19 @@ SIGNATURES = {
                              c_void_p, c_void_p]),
     "sdrm_sample": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_uint64,
                             c_uint64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sdrm_sample_begin": (c_int, [c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_uint64, c_uint64, c_int64, c_void_p, c_void_p]),
+    "sdrm_sample_steps": (c_int, [c_void_p, c_int, c_void_p]),
+    "sdrm_sample_remaining": (c_int, [c_void_p]),
+    "sdrm_sample_end": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sdrm_reverse_step": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sdrm_perturb_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "sdrm_get_preacts": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "sdrm_profile_begin": (c_int, [c_void_p, c_int]),
+    "sdrm_profile_end": (c_int, [c_void_p, c_void_p]),
+    "sdrm_profile_classes": (c_int, []),
+    "sdrm_profile_name": (C.c_char_p, [c_int]),
+    "sdrm_profile_get": (c_int, [c_void_p, c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "sdrm_build_info": (C.c_char_p, []),
     "sdrm_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }

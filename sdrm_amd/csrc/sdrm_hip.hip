@@ -50,8 +50,30 @@ struct sdrm_engine {
   const float* cur_x0 = nullptr;
   bool fwd_done = false;
   int last_S = 1, last_dgrad_blocks = 0;
+  struct SampleStateT {
+    bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
+    uint64_t seed, call_id; int64_t row0;
+  } smp = {false, 0, 0, 0, 0, 0, 1.f, nullptr, nullptr, 0, 0, 0};
+  // event profiling (bench only)
+  bool prof_on = false;
+  int prof_cap = 0;
+  std::vector<hipEvent_t> prof_ev;      // 2 per recorded launch
+  std::vector<int> prof_cls;
+  std::vector<double> prof_flops;
+  double prof_ms[16] = {0};
+  double prof_fl[16] = {0};
+  int64_t prof_n[16] = {0};
   std::string err;
 };
+
+typedef sdrm_engine::SampleStateT SampleState;
+
+enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_FWD_OUT_REVERSE, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_COUNT };
+static const char* kProfNames[PC_COUNT] = {
+    "gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
+    "gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)", "gemm_kernel<0,0,1,0,2> fwd out + reverse update",
+    "gemm_kernel<0,1,0,0,3> dgrad (prelu' epilogue)", "gemm_kernel<1,1,0,1,4> wgrad (prelu-in, split-K slabs)",
+    "gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)"};
 
 namespace {
 
@@ -80,42 +102,56 @@ float* pre_buf(sdrm_engine* e, int k) { return e->pre + (size_t)k * e->MPmax * e
 const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? e->off_a0 : e->off_ah); }
 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
+struct Prof { sdrm_engine* e; int cls; double flops; };
+
 template <int LA, int LB, int XA, int XB, int EPI>
-hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st) {
+hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0}) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   a.tiles_n = tiles_n;
   a.nblocks = tiles_m * tiles_n;
   dim3 grid(a.nblocks, 1, splits);
+  sdrm_engine* e = pr.e;
+  const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(pr.cls);
+    e->prof_flops.push_back(pr.flops);
+    hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
+    if (st0 != hipSuccess) return st0;
+  }
   hipLaunchKernelGGL((gemm_kernel<LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
-  return hipGetLastError();
+  hipError_t rc = hipGetLastError();
+  if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
+  return rc;
 }
 
 // forward Linear: C[M,N] = act(xf(A)[M,K] * Wc[N,K]^T + bias)
 template <int XA, int EPI>
 hipError_t gemm_forward(GemmArgs a, const float* A, int lda, const float* Wc, int ldw, int M, int N, int K,
-                        hipStream_t st) {
+                        hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0}) {
   a.A = A; a.lda = lda; a.limA = M;
   a.B = Wc; a.ldb = ldw; a.limB = N;
   a.K = K; a.kchunk = K;
-  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st);
+  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st, pr);
 }
 
 // dgrad: C[M,Kin] = (dC[M,Nout] * Wc[Nout,Kin]) * prelu'(aux)
 hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* Wc, int ldw, int M, int Nout, int Kin,
-                      float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st) {
+                      float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st, double flops) {
   GemmArgs a{};
   a.A = dC; a.lda = lddc; a.limA = M;
   a.B = Wc; a.ldb = ldw; a.limB = Kin;
   a.C = out; a.ldc = e->WP;
   a.K = Nout; a.kchunk = Nout;
   a.aux = aux; a.ldaux = e->WP; a.slopeE = slopeE; a.slope_partial = partial;
-  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st);
+  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st, Prof{e, PC_DGRAD, flops});
 }
 
 // wgrad: slab[s][Nout,Kin] = dC[rows s][.,Nout]^T * xf(Act)[rows s][., Kin] ; dbias[s][Nout] = column sums of dC
 template <int XB>
 hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int ldact, int Kin, const float* slopeB,
-                      int Mrows, int S, int kchunk, float* slab, float* dbias, hipStream_t st) {
+                      int Mrows, int S, int kchunk, float* slab, float* dbias, hipStream_t st, Prof pr) {
   GemmArgs a{};
   a.A = dC; a.lda = lddc; a.limA = Nout;
   a.B = Act; a.ldb = ldact; a.limB = Kin;
@@ -124,7 +160,7 @@ hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int
   a.slopeB = slopeB;
   a.slab_stride = (size_t)Nout * Kin;
   a.dbias = dbias; a.dbias_stride = Nout;
-  return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st);
+  return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st, pr);
 }
 
 void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
@@ -196,11 +232,13 @@ int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
 
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
 // (its bias / K differ between training and sampling).
-int hidden_forward(sdrm_engine* e, int MP, hipStream_t st) {
+int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st) {
+  const double fl = 2.0 * rows * (double)e->W * e->W;
   for (int k = 1; k <= e->H; ++k) {
     GemmArgs a{};
     a.C = pre_buf(e, k); a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
-    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1), e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st)));
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1), e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
+                                                 Prof{e, PC_FWD_HIDDEN, fl})));
   }
   return SDRM_OK;
 }
@@ -333,6 +371,7 @@ int sdrm_destroy(sdrm_engine* e) {
                   e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   delete e;
   return SDRM_OK;
 }
@@ -429,15 +468,17 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   {
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
-    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st)));
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
+                                                Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)})));
   }
-  rc = hidden_forward(e, MP, st);
+  rc = hidden_forward(e, MP, 3 * B, st);
   if (rc) return rc;
   {
     GemmArgs a{};
     a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
     a.rows_valid = MP; a.cols_valid = e->LP;
-    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
+                                                      Prof{e, PC_FWD_OUT, 2.0 * 3 * B * (double)e->L * e->W})));
   }
   LossArgs la{};
   la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
@@ -469,23 +510,26 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   pick_splits(MP, e->LP, e->WP, SO, kcO);
   const int dgrad_blocks = (MP / BM) * ((e->WP + BN - 1) / BN);
   // output layer
+  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W,
+               fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
   HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, kcO,
-                                   e->slabO, e->dbOs, st)));
+                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
   float* dcur = e->dA;
   float* dnext = e->dB;
   HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->Woc, e->WP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
-                        e->alpha_part + (size_t)H * e->alpha_part_stride, st));
+                        e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO));
   // shared hidden layer, applications H..1
   for (int k = H; k >= 1; --k) {
     HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dcur, e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
                                      kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
-                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st)));
+                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
     HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
-                          slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st));
+                          slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH));
     float* tmp = dcur; dcur = dnext; dnext = tmp;
   }
   // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
-  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st)));
+  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                  Prof{e, PC_WGRAD_L0, fl0})));
   EmbBwdArgs ea{};
   ea.slab0 = e->slab0; ea.slab_stride = (size_t)e->WP * e->K0; ea.S = S0;
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dC0 = e->dC0; ea.dE = e->dE; ea.g = e->g;
@@ -550,14 +594,16 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
   {
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
-    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st)));
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
+                                                Prof{e, PC_FWD_L0, 2.0 * n * (double)e->W * (e->L + e->T)})));
   }
-  rc = hidden_forward(e, MP, st);
+  rc = hidden_forward(e, MP, n, st);
   if (rc) return rc;
   GemmArgs a{};
   a.C = out; a.ldc = ldout; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
   a.rows_valid = n; a.cols_valid = cols_valid;
-  HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+  HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
+                                                    Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W})));
   return SDRM_OK;
 }
 
@@ -595,14 +641,16 @@ int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const f
   return SDRM_OK;
 }
 
-int sdrm_sample(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
-                const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0, float* out,
-                int64_t* Tj_out, void* stream) {
-  if (!e || !out) return fail(e, SDRM_ERR_ARG, "sdrm_sample: null pointer");
+int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
+                      const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0,
+                      int64_t* Tj_out, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  e->smp.active = false;
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: n outside [1, 3*max_rows]");
   if (mode == SDRM_RNG_EXPLICIT && (!xT || !z || !keep || (multires && !Tj)))
     return fail(e, SDRM_ERR_ARG, "sdrm_sample: EXPLICIT mode needs xT, z, keep (and Tj for multi-resolution)");
   if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
+  if (multires && n > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: multi-resolution n > max_rows");
   hipStream_t st = (hipStream_t)stream;
   const int T = e->T, L = e->L, MP = round_up(n, BM);
   e->fwd_done = false;
@@ -617,35 +665,119 @@ int sdrm_sample(sdrm_engine* e, int n, float nd, int multires, int mode, const f
   ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T; ia.i_start = i_start;
   ia.mode = mode; ia.multires = multires; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
-  if (multires && n > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: multi-resolution n > max_rows");
-  {
-    dim3 grid((e->LP / 2 + 255) / 256, MP);
-    hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
-    HIP_TRY(e, hipGetLastError());
-  }
-  for (int i = i_start; i >= 1; --i) {
+  dim3 grid((e->LP / 2 + 255) / 256, MP);
+  hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
+  HIP_TRY(e, hipGetLastError());
+  e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0};
+  return SDRM_OK;
+}
+
+int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_steps: no sampling call in progress");
+  hipStream_t st = (hipStream_t)stream;
+  SampleState& s = e->smp;
+  const int n = s.n, MP = s.MP, L = e->L;
+  const size_t nL = (size_t)n * L;
+  for (int done = 0; done < count && s.i_next >= 1; ++done, --s.i_next) {
+    const int i = s.i_next;
     {
       GemmArgs a{};
       a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
-      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st)));
+      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
+                                                  Prof{e, PC_FWD_L0, 2.0 * n * (double)e->W * (e->L + e->T)})));
     }
-    rc = hidden_forward(e, MP, st);
+    int rc = hidden_forward(e, MP, n, st);
     if (rc) return rc;
     GemmArgs a{};
     a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
     a.ldc = e->LP; a.rows_valid = n; a.Lreal = L;
     a.X = e->X; a.Unext = e->U; a.ldu = e->K0;
-    a.Z = (mode == SDRM_RNG_EXPLICIT && i > 1) ? z + (size_t)i * nL : nullptr;
-    a.keep_next = (mode == SDRM_RNG_EXPLICIT && i > 1) ? keep + (size_t)(i - 1) * nL : nullptr;
-    a.Tj = multires ? e->Tj_dev : nullptr;
-    a.step_i = i; a.nd = nd;
+    a.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
+    a.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
+    a.Tj = s.multires ? e->Tj_dev : nullptr;
+    a.step_i = i; a.nd = s.nd;
     reverse_coeffs(e, i, a.c1, a.sqrt_alpha, a.sqrt_beta);
-    a.rng_mode = mode; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.call_id = (uint32_t)call_id;
-    a.row0 = row0;
-    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REVERSE>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st)));
+    a.rng_mode = s.mode; a.seed_lo = (uint32_t)s.seed; a.seed_hi = (uint32_t)(s.seed >> 32);
+    a.call_id = (uint32_t)s.call_id; a.row0 = s.row0;
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REVERSE>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
+                                                         Prof{e, PC_FWD_OUT_REVERSE, 2.0 * n * (double)e->L * e->W})));
   }
-  hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, st, (const float*)e->X, e->LP, out, n, L);
+  return SDRM_OK;
+}
+
+int sdrm_sample_remaining(const sdrm_engine* e) { return (e && e->smp.active) ? e->smp.i_next : 0; }
+
+int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
+  if (!e || !out) return SDRM_ERR_ARG;
+  if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
+  if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
+  hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
+                     e->smp.n, e->L);
   HIP_TRY(e, hipGetLastError());
+  e->smp.active = false;
+  return SDRM_OK;
+}
+
+int sdrm_sample(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
+                const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0, float* out,
+                int64_t* Tj_out, void* stream) {
+  if (!e || !out) return fail(e, SDRM_ERR_ARG, "sdrm_sample: null pointer");
+  int rc = sdrm_sample_begin(e, n, nd, multires, mode, xT, z, keep, Tj, seed, call_id, row0, Tj_out, stream);
+  if (rc) return rc;
+  rc = sdrm_sample_steps(e, e->T + 1, stream);
+  if (rc) return rc;
+  return sdrm_sample_end(e, out, stream);
+}
+
+int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) {
+  if (!e || !out) return SDRM_ERR_ARG;
+  sdrm_engine* me = const_cast<sdrm_engine*>(e);
+  if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
+  if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
+  hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
+                     e->cur_B, e->W, e->WP, out);
+  HIP_TRY(me, hipGetLastError());
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int sdrm_profile_classes(void) { return PC_COUNT; }
+const char* sdrm_profile_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
+
+int sdrm_profile_begin(sdrm_engine* e, int capacity) {
+  if (!e || capacity < 1) return SDRM_ERR_ARG;
+  while ((int)e->prof_ev.size() < 2 * capacity) {
+    hipEvent_t ev;
+    HIP_TRY(e, hipEventCreate(&ev));
+    e->prof_ev.push_back(ev);
+  }
+  e->prof_cap = capacity;
+  e->prof_cls.clear();
+  e->prof_flops.clear();
+  for (int i = 0; i < 16; ++i) { e->prof_ms[i] = 0; e->prof_fl[i] = 0; e->prof_n[i] = 0; }
+  e->prof_on = true;
+  return SDRM_OK;
+}
+
+int sdrm_profile_end(sdrm_engine* e, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  e->prof_on = false;
+  HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+  for (size_t i = 0; i < e->prof_cls.size(); ++i) {
+    float ms = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]));
+    const int c = e->prof_cls[i];
+    e->prof_ms[c] += ms; e->prof_fl[c] += e->prof_flops[i]; e->prof_n[c] += 1;
+  }
+  return SDRM_OK;
+}
+
+int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* launches, double* flops) {
+  if (!e || cls < 0 || cls >= PC_COUNT) return SDRM_ERR_ARG;
+  if (total_ms) *total_ms = e->prof_ms[cls];
+  if (launches) *launches = e->prof_n[cls];
+  if (flops) *flops = e->prof_fl[cls];
   return SDRM_OK;
 }
 

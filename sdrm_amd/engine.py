@@ -177,6 +177,27 @@ class Engine:
         self._check(self.lib.sdrm_get_train_outputs(self._h, _ptr(out), _stream()), "sdrm_get_train_outputs")
         return out
 
+    def preacts(self, layer, B):
+        """Pre-activations [3,B,W] of layer `layer` from the last train forward (parity tests)."""
+        out = torch.empty(3, B, self.W, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_get_preacts(self._h, int(layer), _ptr(out), _stream()), "sdrm_get_preacts")
+        return out
+
+    # ------------------------------------------------------------------ profiling (bench only)
+    def profile_begin(self, capacity=4096):
+        self._check(self.lib.sdrm_profile_begin(self._h, int(capacity)), "sdrm_profile_begin")
+
+    def profile_end(self):
+        """Returns {kernel class name: (total_ms, launches, algorithmic_flops)} for classes that ran."""
+        self._check(self.lib.sdrm_profile_end(self._h, _stream()), "sdrm_profile_end")
+        out = {}
+        for c in range(self.lib.sdrm_profile_classes()):
+            ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+            self._check(self.lib.sdrm_profile_get(self._h, c, C.byref(ms), C.byref(n), C.byref(fl)), "sdrm_profile_get")
+            if n.value:
+                out[self.lib.sdrm_profile_name(c).decode()] = (ms.value, int(n.value), fl.value)
+        return out
+
     # ------------------------------------------------------------------ inference
     def forward(self, x, t, keep=None, seed=0, step=0, row0=0):
         """SDRM.forward(x, t) (:97-103); dropout is always on (Q2)."""
@@ -213,6 +234,22 @@ class Engine:
         self._check(rc, "sdrm_sample")
         self._keepalive = (xT, z, keep, Tj)
         return (out, tj_out) if return_Tj else out
+
+    def sample_begin(self, n, nd=1.0, multires=False, seed=0, call_id=0, row0=0):
+        """Resumable PHILOX-mode sampler (bench.py interleaves its steps with train steps)."""
+        self._check(self.lib.sdrm_sample_begin(self._h, int(n), float(nd), int(bool(multires)), _lib.RNG_PHILOX, None,
+                                               None, None, None, int(seed), int(call_id), int(row0), None, _stream()),
+                    "sdrm_sample_begin")
+        self._sample_n = int(n)
+
+    def sample_steps(self, count):
+        self._check(self.lib.sdrm_sample_steps(self._h, int(count), _stream()), "sdrm_sample_steps")
+        return int(self.lib.sdrm_sample_remaining(self._h))
+
+    def sample_end(self):
+        out = torch.empty(self._sample_n, self.L, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_sample_end(self._h, _ptr(out), _stream()), "sdrm_sample_end")
+        return out
 
     def reverse_step(self, x, i, z, keep):
         x = self._dev(x, torch.float32).clone()

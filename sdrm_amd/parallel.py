@@ -1,0 +1,58 @@
+"""User-sharded (data-parallel) train step: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-device; this is new functionality specified in SURVEY.md
+§8e.  Rows (users) of the global batch are partitioned contiguously over ranks.  Two exchanges per
+step, nothing else:
+
+  1. all-reduce(sum) of 5 float64 loss scalars {sum D^2, sum (R-S)^2, sum R, sum R^2, count} after the
+     three forwards: var(R) and both mse means of `score_matching_loss` (train_SDRM.py:196-198) are
+     over the GLOBAL batch, and the gradient flows through them (Q6).
+  2. all-reduce(sum) of the flat gradient [P] fp32; every rank then applies the identical Adam update
+     (train_SDRM.py:337), so parameters stay replicated without a broadcast.
+
+Randomness is Philox keyed by the GLOBAL row index, so G ranks draw exactly what one rank draws.
+Sampling shards users with no communication at all.
+
+The trainer only needs an object with `train_forward / train_backward / adam_step` (the three phases
+of include/sdrm_hip.h); the CPU tests drive it with an oracle-backed stand-in over gloo."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Contiguous balanced partition: first (n_rows % world) ranks get one extra row."""
+    base, extra = divmod(n_rows, world)
+    start = rank * base + min(rank, extra)
+    return start, base + (1 if rank < extra else 0)
+
+
+class ShardedTrainer:
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None):
+        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+        dev = device if device is not None else getattr(engine, "device", "cpu")
+        P = n_params if n_params is not None else engine.P
+        self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.grad = torch.zeros(P, dtype=torch.float32, device=dev)
+
+    def train_step(self, x0_local, lr, row0=0, step=0, seed=0, nd=1.0, explicit=None):
+        """x0_local: this rank's rows [rows, L].  explicit = (noise, t, keep) for this rank's rows,
+        or None for Philox(seed, step, row0 + r, c).  Returns the device scalar holding the GLOBAL loss."""
+        e = self.engine
+        if self.world == 1:
+            if explicit is None:
+                return e.train_step(x0_local, lr, seed=seed, step=step, nd=nd)
+            noise, t, keep = explicit
+            return e.train_step(x0_local, lr, noise=noise, t=t, keep=keep, nd=nd)
+        if explicit is None:
+            e.train_forward(x0_local, seed=seed, step=step, nd=nd, row0=row0, sums=self.sums)
+        else:
+            noise, t, keep = explicit
+            e.train_forward(x0_local, noise=noise, t=t, keep=keep, nd=nd, row0=row0, sums=self.sums)
+        dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
+        loss = e.train_backward(sums=self.sums, grad=self.grad)
+        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+        e.adam_step(lr, grad=self.grad)
+        return loss
