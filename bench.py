@@ -88,12 +88,25 @@ class Job:
         return kind
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: the cgroup CPU quota if there is one (the GPU box exposes
+    256 logical CPUs but grants 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(wl, seconds_budget=25.0):
     """The CPU oracle (torch CPU ops, all host cores) on the same step mix: one whole job cycle if it
     fits the budget, else a proportional prefix."""
     from oracle import sdrm_oracle as orc
     L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     o = orc.Oracle(L, W, T, H, synth.init_params(L, W, T, H, seed=1))
     x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0))

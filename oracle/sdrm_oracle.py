@@ -110,23 +110,30 @@ class Oracle:
             cache.update(t=t, u=u, pre=pre, h=h, y=y)
         return y
 
-    def backward(self, cache, gy, grads):
-        """Accumulate parameter gradients of one pass given dL/dy (no latent dgrad, Q7)."""
+    def backward(self, cache, gy, grads, neg_override=None):
+        """Accumulate parameter gradients of one pass given dL/dy (no latent dgrad, Q7).
+
+        `neg_override` (list of H+1 bool tensors, True = take the slope branch) replaces the sign
+        test on the pre-activations.  PReLU'(v) jumps at v = 0, so two fp32 implementations whose
+        pre-activations differ in the last bit can legitimately pick different branches for an element
+        that is zero within rounding; parity tests pass the HIP engine's own branch choice here after
+        checking that it differs from the oracle's only at such elements ("kink flips")."""
         p, L = self.p, self.L
         y, pre, h, u, t = cache["y"], cache["pre"], cache["h"], cache["u"], cache["t"]
+        negs = neg_override if neg_override is not None else [q <= 0 for q in pre]
         wl, bl = f"dnn.{self.last}.weight", f"dnn.{self.last}.bias"
         d = gy * (1 - y * y)
         grads[wl] += d.T @ h[-1]
         grads[bl] += d.sum(0)
         dh = d @ p[wl]
         for k in range(self.H, 0, -1):
-            neg = pre[k] <= 0  # torch prelu backward: input > 0 ? g : a*g
+            neg = negs[k]  # torch prelu backward: input > 0 ? g : a*g
             grads["dnn.3.weight"] += (dh * torch.where(neg, pre[k], torch.zeros(()))).sum().reshape(1)
             d = dh * torch.where(neg, p["dnn.3.weight"], torch.ones(()))
             grads["dnn.2.weight"] += d.T @ h[k - 1]
             grads["dnn.2.bias"] += d.sum(0)
             dh = d @ p["dnn.2.weight"]
-        neg = pre[0] <= 0
+        neg = negs[0]
         grads["dnn.1.weight"] += (dh * torch.where(neg, pre[0], torch.zeros(()))).sum().reshape(1)
         d = dh * torch.where(neg, p["dnn.1.weight"], torch.ones(()))
         grads["dnn.0.weight"] += d.T @ u
@@ -136,9 +143,11 @@ class Oracle:
         grads["emb_layer.bias"] += de.sum(0)
 
     # ------------------------------------------------------------------ loss
-    def loss_and_grads(self, x0, eps, t, keeps):
+    def loss_and_grads(self, x0, eps, t, keeps, neg_override=None, caches=None):
         """Three forwards + score-matching loss + all parameter gradients.
-        Returns (loss, grads, (P,S,Q), x_pert).  `eps` is already scaled by nd."""
+        Returns (loss, grads, (P,S,Q), x_pert).  `eps` is already scaled by nd.
+        neg_override: optional [3][H+1] branch masks (see `backward`); caches: optional list that
+        receives the three per-pass activation caches."""
         x0, eps = _t(x0), _t(eps)
         t = _t(t, torch.int64)
         keeps = [_t(k) for k in keeps]
@@ -165,9 +174,12 @@ class Oracle:
         gQ = gD / mu2
         gS = -gD / mu2 - gC
         grads = {n: torch.zeros_like(v) for n, v in self.p.items()}
-        self.backward(cP, gP, grads)
-        self.backward(cS, gS, grads)
-        self.backward(cQ, gQ, grads)
+        ov = neg_override if neg_override is not None else [None, None, None]
+        self.backward(cP, gP, grads, ov[0])
+        self.backward(cS, gS, grads, ov[1])
+        self.backward(cQ, gQ, grads, ov[2])
+        if caches is not None:
+            caches.extend([cP, cS, cQ])
         return loss, grads, (P, S, Q), xp
 
     # ------------------------------------------------------------------ optimiser

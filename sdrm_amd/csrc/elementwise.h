@@ -269,41 +269,41 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Embedding-path backward from dC0 (the one-hot columns of the layer-0 weight gradient):
-//   dC0[t][w] = sum_s slab0[s][w][LP+t] ;  dE[t] = dC0[t] * W0[:, L:]
+// Embedding-path backward.  k_grad_finalize first reduces the one-hot columns of the layer-0 weight
+// gradient slabs into a dense dC0T[w][t] = sum over rows with timestep t of dpre0[row][w]  ([W][TP]).
+//   k_emb_bwd1:  dE[t][j]   = sum_w dC0T[w][t] * W0[w][L+j]
+//   k_emb_bwd2:  dW0[w][L+j] = sum_t dC0T[w][t] * E[t][j]
+//                dWe[j][i]  = sum_t dE[t][j] * temb[t][i] ;  dbe[j] = sum_t dE[t][j]
 struct EmbBwdArgs {
-  const float* slab0; size_t slab_stride; int S;
+  const float* dC0T; int TP;
   const float* W0; const float* Etab; const float* temb;
-  float* dC0; float* dE; float* g; int64_t off_we, off_be, off_w0;
-  int L, W, T, LP, K0;
+  float* dE; float* g; int64_t off_we, off_be, off_w0;
+  int L, W, T;
 };
 
-__global__ __launch_bounds__(256) void k_emb_bwd1(const EmbBwdArgs a) {
-  extern __shared__ float sh[];  // [W]
+__global__ __launch_bounds__(128) void k_emb_bwd1(const EmbBwdArgs a) {
   const int t = blockIdx.x;
-  for (int w = threadIdx.x; w < a.W; w += blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < a.S; ++k) s += a.slab0[(size_t)k * a.slab_stride + (size_t)w * a.K0 + a.LP + t];
-    sh[w] = s;
-    a.dC0[(size_t)t * a.W + w] = s;
-  }
-  __syncthreads();
   const int ldw = a.L + a.T;
   for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
-    float s = 0.f;
-    for (int w = 0; w < a.W; ++w) s = fmaf(sh[w], a.W0[(size_t)w * ldw + a.L + j], s);
-    a.dE[(size_t)t * a.T + j] = s;
+    float s0 = 0.f, s1 = 0.f;
+    int w = 0;
+    for (; w + 1 < a.W; w += 2) {
+      s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
+      s1 = fmaf(a.dC0T[(size_t)(w + 1) * a.TP + t], a.W0[(size_t)(w + 1) * ldw + a.L + j], s1);
+    }
+    if (w < a.W) s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
+    a.dE[(size_t)t * a.T + j] = s0 + s1;
   }
 }
 
-//   dW0[:, L+j] = sum_t dC0[t][w] E[t][j] ; dWe[j][i] = sum_t dE[t][j] temb[t][i] ; dbe[j] = sum_t dE[t][j]
 __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
   const int n1 = a.W * a.T, n2 = a.T * a.T, n3 = a.T;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n1) {
     const int w = i / a.T, j = i - w * a.T;
+    const float* dc = a.dC0T + (size_t)w * a.TP;
     float s = 0.f;
-    for (int t = 0; t <= a.T; ++t) s = fmaf(a.dC0[(size_t)t * a.W + w], a.Etab[(size_t)t * a.T + j], s);
+    for (int t = 0; t <= a.T; ++t) s = fmaf(dc[t], a.Etab[(size_t)t * a.T + j], s);
     a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = s;
   } else if (i < n1 + n2) {
     const int k = i - n1;
@@ -328,22 +328,34 @@ struct Job {
   int ncols;          // columns [0,ncols) of each row are covered by this job (dnn.0.weight: L of L+T)
   const float* src; int src_ld; size_t slab_stride; int nslabs;   // finalize source (padded slabs)
   int inner;          // >1: scalar job, sum src[k*slab_stride + q] over k<nslabs, q<inner (slope partials)
+  float* gdst; int g_ld;   // where k_grad_finalize writes: flat gradient (g + flat_off, flat_ld) or a scratch table
   float* dst; int dst_ld;                                          // compute copy (may be null)
 };
 constexpr int MAX_JOBS = 12;
-struct JobTable { Job j[MAX_JOBS]; int n; };
+struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
 
-__global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab, float* g) {
+__global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab) {
   const Job& jb = tab.j[blockIdx.y];
   if (jb.src == nullptr) return;
   const int64_t total = (int64_t)jb.rows * jb.ncols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / jb.ncols), c = (int)(i - (int64_t)r * jb.ncols);
     const float* s = jb.src + (size_t)r * jb.src_ld + c;
-    float acc = 0.f;
-    for (int k = 0; k < jb.nslabs; ++k)
-      for (int q = 0; q < jb.inner; ++q) acc += s[(size_t)k * jb.slab_stride + q];
-    g[jb.flat_off + (int64_t)r * jb.flat_ld + c] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (jb.inner == 1) {
+      int k = 0;
+      for (; k + 3 < jb.nslabs; k += 4) {   // four independent loads in flight per thread
+        a0 += s[(size_t)k * jb.slab_stride];
+        a1 += s[(size_t)(k + 1) * jb.slab_stride];
+        a2 += s[(size_t)(k + 2) * jb.slab_stride];
+        a3 += s[(size_t)(k + 3) * jb.slab_stride];
+      }
+      for (; k < jb.nslabs; ++k) a0 += s[(size_t)k * jb.slab_stride];
+    } else {
+      for (int k = 0; k < jb.nslabs; ++k)
+        for (int q = 0; q < jb.inner; ++q) a0 += s[(size_t)k * jb.slab_stride + q];
+    }
+    jb.gdst[(int64_t)r * jb.g_ld + c] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -407,7 +419,8 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
         const uint32_t grow = (uint32_t)(a.row0 + r);
         const U4 w = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_XT, a.call_id, a.seed_lo, a.seed_hi);
         box_muller(w.x, w.y, nrm[0], nrm[1]);
-        const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)a.i_start << 8), a.call_id,
+        // the keep bits of step i ride on the Philox call that draws z_{i+1} (see EPI_TANH_REVERSE)
+        const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)(a.i_start + 1) << 8), a.call_id,
                                     a.seed_lo, a.seed_hi);
         bits = w2.z;
       }
@@ -425,6 +438,54 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
   }
   *reinterpret_cast<float2*>(a.X + (size_t)r * a.LP + c) = make_float2(x[0], x[1]);
   *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = make_float2(u[0], u[1]);
+}
+
+// One DDPM reverse update on the sampler's padded state (denoise_add_noise, train_SDRM.py:20-25) fused
+// with the next step's input dropout (F.dropout, :100):
+//   x <- (x - eps_hat*c1)/sqrt(alpha_i) + sqrt(beta_i)*z   for rows with Tj >= i (all rows if Tj == null)
+//   U_next = 2*keep_{i-1}*x
+// One thread per column pair: in PHILOX mode one Philox call yields the pair's two normals z_i and the
+// pair's keep bits for step i-1.
+struct ReverseArgs {
+  float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj;
+  int n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
+  int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
+};
+
+__global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
+  const int r = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int c = 2 * q;
+  if (c >= a.L || r >= a.n) return;
+  const size_t xi = (size_t)r * a.LP + c;
+  const float2 xo = *reinterpret_cast<const float2*>(a.X + xi);
+  const float2 e = *reinterpret_cast<const float2*>(a.Y + xi);
+  const bool active = (a.Tj == nullptr) || (a.Tj[r] >= (int64_t)a.step_i);
+  float z[2] = {0.f, 0.f};
+  bool kp[2] = {false, false};
+  if (a.step_i > 1) {
+    if (a.mode == 0) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (c + j < a.L) {
+          const size_t idx = (size_t)r * a.L + c + j;
+          z[j] = a.Z[idx];
+          kp[j] = a.keep_next[idx] != 0;
+        }
+    } else {
+      const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)a.step_i << 8),
+                                 a.call_id, a.seed_lo, a.seed_hi);
+      box_muller(w.x, w.y, z[0], z[1]);
+      z[0] *= a.nd; z[1] *= a.nd;
+      kp[0] = w.z & 1u; kp[1] = (w.z >> 8) & 1u;
+    }
+  }
+  float xn[2];
+  xn[0] = active ? (xo.x - e.x * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[0] : xo.x;
+  xn[1] = (c + 1 < a.L) ? (active ? (xo.y - e.y * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[1] : xo.y) : 0.f;
+  *reinterpret_cast<float2*>(a.X + xi) = make_float2(xn[0], xn[1]);
+  if (a.step_i > 1)
+    *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = make_float2(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L) {

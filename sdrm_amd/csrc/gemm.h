@@ -6,16 +6,23 @@
 // (As[k][i], Bs[k][j]), which is the layout v_mfma_f32_32x32x2_f32 consumes with
 // conflict-free ds_read_b32: lane l reads As[k0 + (l>>5)][i0 + (l&31)].
 //
-//   block tile 128x128, K-step 16, 256 threads = 4 waves as 2(M) x 2(N),
-//   each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs),
-//   LDS double-buffered (2 x 2 x 16 x 132 floats = 33 KB), one barrier per K-step,
-//   global->register prefetch of the next K-step issued before the MFMAs of the current one.
+//   block tile BM x BN (template), K-step 16, 256 threads = 4 waves as WM x WN,
+//   each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each),
+//   LDS double-buffered, one barrier per K-step, global->register prefetch of the next K-step
+//   issued before the MFMAs of the current one, all fragments of a K-step read into registers
+//   ahead of its MFMAs (the compiler places counted lgkmcnt waits).
 //
-// fp32-input MFMA is bit-for-bit a k-ordered fmaf chain, so the results sit well inside the 1e-4
+// MFMAs are issued unconditionally: operand rows/cols beyond the matrix are zero-filled in LDS, and
+// a work-group is as slow as its busiest wave anyway, so predicating whole MFMA tiles buys nothing
+// and costs exec-mask branches around every MFMA.
+//
+// fp32-input MFMA is bit-for-bit a k-ordered fmaf chain, so results sit well inside the 1e-4
 // normwise parity bar.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "philox.h"
 
 namespace sdrm {
 
@@ -26,13 +33,22 @@ enum : int { XF_NONE = 0, XF_PRELU = 1 };
 enum : int {
   EPI_BIAS = 0,          // C = acc + bias[n]                         (hidden pre-activations)
   EPI_BIAS_TANH = 1,     // C = tanh(acc + bias[n])                   (eps-net output)
-  EPI_TANH_REVERSE = 2,  // fused DDPM reverse update + next step's dropout (sampling)
   EPI_DPRELU = 3,        // C = acc * prelu'(aux) ; partial sum of acc*min(aux,0) (slope gradient)
   EPI_SLAB = 4,          // C = acc into split-K slab blockIdx.z ; optional column sums (bias grad)
   EPI_PLAIN = 5          // C = acc (debug)
 };
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BM + 4, NTHREADS = 256;
+constexpr int BK = 16, NTHREADS = 256;
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;   // MFMA tiles per wave
+  static constexpr int LDA = BM_ + 4, LDB = BN_ + 4;               // LDS row strides (floats)
+  static constexpr int STAGE = BK * (LDA + LDB);                   // floats per pipeline stage
+  static_assert(WM_ * WN_ == 4, "4 waves per work-group");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+};
 
 struct GemmArgs {
   const float* A; int lda; int limA;   // limA: valid extent of A's output-side index (multiple of 32)
@@ -40,7 +56,7 @@ struct GemmArgs {
   float* C; int ldc;
   int K;            // full reduction length (multiple of BK)
   int kchunk;       // reduction range handled by one blockIdx.z (multiple of BK)
-  int tiles_n;      // number of 128-wide tiles along N (grid.x = tiles_m * tiles_n, XCD-swizzled)
+  int tiles_n;      // number of tiles along N (grid.x = tiles_m * tiles_n, XCD-swizzled)
   int nblocks;      // tiles_m * tiles_n
   const float* bias;
   const float* slopeA;  // PReLU slope applied to A elements on load (XF_PRELU)
@@ -51,26 +67,25 @@ struct GemmArgs {
   size_t slab_stride; float* dbias; int dbias_stride;
   // EPI_BIAS_TANH: output may be an unpadded caller buffer
   int rows_valid, cols_valid;
-  // EPI_TANH_REVERSE
-  float* X; const float* Z; const uint8_t* keep_next; float* Unext; int ldu;
-  const int64_t* Tj; int step_i; float c1, sqrt_alpha, sqrt_beta, nd;
-  int rng_mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0; int Lreal;
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
 
-template <int LOAD, int XF>
+// Global -> registers for one operand tile (ROWS x BK elements, ROWS = BM or BN).
+template <int LOAD, int XF, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int i0, int lim, int k0,
-                                          float slope, float4 (&r)[2], int tid) {
+                                          float slope, float4 (&r)[ROWS * BK / 4 / NTHREADS], int tid) {
+  constexpr int NV = ROWS * BK / 4 / NTHREADS;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOAD == LD_KCONTIG) {
       const int i = f >> 2, kq = f & 3;
       if (i0 + i < lim) v = *reinterpret_cast<const float4*>(src + (size_t)(i0 + i) * ld + k0 + 4 * kq);
     } else {
-      const int k = f >> 5, iq = f & 31;
+      constexpr int VPR = ROWS / 4;  // float4 per k-row
+      const int k = f / VPR, iq = f - k * VPR;
       if (i0 + 4 * iq < lim) v = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + i0 + 4 * iq);
     }
     if (XF == XF_PRELU) {
@@ -80,18 +95,22 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
   }
 }
 
-template <int LOAD>
-__device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4 (&r)[2], int tid) {
+// Registers -> LDS (k-major, row stride LD).
+template <int LOAD, int ROWS, int LD>
+__device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4 (&r)[ROWS * BK / 4 / NTHREADS],
+                                           int tid) {
+  constexpr int NV = ROWS * BK / 4 / NTHREADS;
 #pragma unroll
-  for (int s = 0; s < 2; ++s) {
+  for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
     if (LOAD == LD_KCONTIG) {
       const int i = f >> 2, kq = f & 3;
-      float* d = dst + (4 * kq) * LDT + i;
-      d[0] = r[s].x; d[LDT] = r[s].y; d[2 * LDT] = r[s].z; d[3 * LDT] = r[s].w;
+      float* d = dst + (4 * kq) * LD + i;
+      d[0] = r[s].x; d[LD] = r[s].y; d[2 * LD] = r[s].z; d[3 * LD] = r[s].w;
     } else {
-      const int k = f >> 5, iq = f & 31;
-      *reinterpret_cast<float4*>(dst + k * LDT + 4 * iq) = r[s];
+      constexpr int VPR = ROWS / 4;
+      const int k = f / VPR, iq = f - k * VPR;
+      *reinterpret_cast<float4*>(dst + k * LD + 4 * iq) = r[s];
     }
   }
 }
@@ -104,19 +123,16 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
-}  // namespace sdrm
-
-// ---------------------------------------------------------------------------------------------
-#include "philox.h"
-
-namespace sdrm {
-
-template <int LOADA, int LOADB, int XFA, int XFB, int EPI>
+template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BK * LDT];
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, TM = Cfg::TM, TN = Cfg::TN, LDA = Cfg::LDA, LDB = Cfg::LDB;
+  constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
+  static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
+  __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   const int logical = xcd_remap(blockIdx.x, p.nblocks);
@@ -128,127 +144,122 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
   const float slopeA = (XFA == XF_PRELU) ? *p.slopeA : 0.f;
   const float slopeB = (XFB == XF_PRELU) ? *p.slopeB : 0.f;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // wave-uniform validity of the four 32x32 MFMA tiles (feature dims are multiples of 32)
-  bool vm[2], vn[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    vm[a] = (m0 + wm * 64 + a * 32) < p.limA;
-    vn[a] = (n0 + wn * 64 + a * 32) < p.limB;
-  }
-
-  float4 ra[2], rb[2];
+  float4 ra[NVA], rb[NVB];
   float dbsum = 0.f;
   const bool do_dbias = (EPI == EPI_SLAB) && (p.dbias != nullptr) && (tile_n == 0) && (tid < BM);
 
   int stage = 0;
   if (kb < ke) {
-    load_tile<LOADA, XFA>(p.A, p.lda, m0, p.limA, kb, slopeA, ra, tid);
-    load_tile<LOADB, XFB>(p.B, p.ldb, n0, p.limB, kb, slopeB, rb, tid);
-    store_tile<LOADA>(smem, ra, tid);
-    store_tile<LOADB>(smem + BK * LDT, rb, tid);
+    load_tile<LOADA, XFA, BM>(p.A, p.lda, m0, p.limA, kb, slopeA, ra, tid);
+    load_tile<LOADB, XFB, BN>(p.B, p.ldb, n0, p.limB, kb, slopeB, rb, tid);
+    store_tile<LOADA, BM, LDA>(smem, ra, tid);
+    store_tile<LOADB, BN, LDB>(smem + BK * LDA, rb, tid);
   }
   __syncthreads();
 
+  const int aoff = lhi * LDA + wm * (BM / Cfg::WM) + l31;
+  const int boff = lhi * LDB + wn * (BN / Cfg::WN) + l31;
+
   for (int kt = kb; kt < ke; kt += BK) {
-    const float* As = smem + stage * (2 * BK * LDT);
-    const float* Bs = As + BK * LDT;
+    const float* As = smem + stage * Cfg::STAGE;
+    const float* Bs = As + BK * LDA;
     const bool more = (kt + BK) < ke;
     if (more) {
-      load_tile<LOADA, XFA>(p.A, p.lda, m0, p.limA, kt + BK, slopeA, ra, tid);
-      load_tile<LOADB, XFB>(p.B, p.ldb, n0, p.limB, kt + BK, slopeB, rb, tid);
+      load_tile<LOADA, XFA, BM>(p.A, p.lda, m0, p.limA, kt + BK, slopeA, ra, tid);
+      load_tile<LOADB, XFB, BN>(p.B, p.ldb, n0, p.limB, kt + BK, slopeB, rb, tid);
     }
+    // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
+    // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
+    float af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float* ap = As + (kk + lhi) * LDT + wm * 64 + l31;
-      const float* bp = Bs + (kk + lhi) * LDT + wn * 64 + l31;
-      const float a0 = ap[0], a1 = ap[32];
-      const float b0 = bp[0], b1 = bp[32];
-      if (vm[0] && vn[0]) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      if (vm[0] && vn[1]) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      if (vm[1] && vn[0]) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      if (vm[1] && vn[1]) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + 32 * a];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + 32 * b];
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 2) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + 2 * (s + 1) * LDA + 32 * a];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + 2 * (s + 1) * LDB + 32 * b];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_dbias) {
 #pragma unroll
-      for (int k = 0; k < BK; ++k) dbsum += As[k * LDT + tid];
+      for (int k = 0; k < BK; ++k) dbsum += As[k * LDA + tid];
     }
     if (more) {
-      float* An = smem + (stage ^ 1) * (2 * BK * LDT);
-      store_tile<LOADA>(An, ra, tid);
-      store_tile<LOADB>(An + BK * LDT, rb, tid);
+      float* An = smem + (stage ^ 1) * Cfg::STAGE;
+      store_tile<LOADA, BM, LDA>(An, ra, tid);
+      store_tile<LOADB, BN, LDB>(An + BK * LDA, rb, tid);
     }
     __syncthreads();
     stage ^= 1;
   }
 
   // ------------------------------------------------------------------ epilogue
-  // accumulator register r of tile (a,b): row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*lhi,
-  //                                        col = n0 + wn*64 + b*32 + l31
+  // accumulator register r of tile (a,b): row = m0 + wm*(BM/WM) + a*32 + (r&3) + 8*(r>>2) + 4*lhi,
+  //                                        col = n0 + wn*(BN/WN) + b*32 + l31
   float slope_sum = 0.f;
   const float slopeE = (EPI == EPI_DPRELU) ? *p.slopeE : 0.f;
+  float* __restrict__ Cp = p.C;
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
+  for (int a = 0; a < TM; ++a) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      if (!(vm[a] && vn[b])) continue;
-      const int col = n0 + wn * 64 + b * 32 + l31;
-      const int rbase = m0 + wm * 64 + a * 32 + 4 * lhi;
+    for (int b = 0; b < TN; ++b) {
+      const int tm0 = m0 + wm * (BM / Cfg::WM) + a * 32, tn0 = n0 + wn * (BN / Cfg::WN) + b * 32;
+      if (tm0 >= p.limA || tn0 >= p.limB) continue;  // wave-uniform: tile entirely outside the matrix
+      const int col = tn0 + l31;
+      const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_TANH_REVERSE) bias = p.bias[col];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) bias = p.bias[col];
+      if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + (r & 3) + 8 * (r >> 2);
-        const float v = acc[a][b][r];
-        if (EPI == EPI_BIAS) {
-          p.C[(size_t)row * p.ldc + col] = v + bias;
-        } else if (EPI == EPI_PLAIN) {
-          p.C[(size_t)row * p.ldc + col] = v;
-        } else if (EPI == EPI_BIAS_TANH) {
-          if (row < p.rows_valid && col < p.cols_valid) p.C[(size_t)row * p.ldc + col] = tanhf(v + bias);
-        } else if (EPI == EPI_DPRELU) {
-          const float pre = p.aux[(size_t)row * p.ldaux + col];
-          const bool pos = pre > 0.f;
-          p.C[(size_t)row * p.ldc + col] = pos ? v : slopeE * v;
-          slope_sum += pos ? 0.f : v * pre;
-        } else if (EPI == EPI_SLAB) {
-          p.C[(size_t)blockIdx.z * p.slab_stride + (size_t)row * p.ldc + col] = v;
-        } else if (EPI == EPI_TANH_REVERSE) {
-          if (row < p.rows_valid && col < p.Lreal) {
-            const float eps_hat = tanhf(v + bias);
-            const size_t xi = (size_t)row * p.ldc + col;
-            const float x_old = p.X[xi];
-            const bool active = (p.Tj == nullptr) || (p.Tj[row] >= (int64_t)p.step_i);
-            float z = 0.f;
-            bool keep = false;
-            if (p.rng_mode == 0) {
-              if (p.Z != nullptr) z = p.Z[(size_t)row * p.Lreal + col];
-              if (p.keep_next != nullptr) keep = p.keep_next[(size_t)row * p.Lreal + col] != 0;
-            } else {
-              const uint32_t grow = (uint32_t)(p.row0 + row);
-              if (p.step_i > 1) {
-                const U4 w = philox4x32_10(grow, (uint32_t)(col >> 1), PURPOSE_SAMPLE_STEP | ((uint32_t)p.step_i << 8),
-                                           p.call_id, p.seed_lo, p.seed_hi);
-                float n0f, n1f;
-                box_muller(w.x, w.y, n0f, n1f);
-                z = ((col & 1) ? n1f : n0f) * p.nd;
-                const U4 w2 = philox4x32_10(grow, (uint32_t)(col >> 1),
-                                            PURPOSE_SAMPLE_STEP | ((uint32_t)(p.step_i - 1) << 8), p.call_id,
-                                            p.seed_lo, p.seed_hi);
-                keep = ((w2.z >> ((col & 1) * 8)) & 1u) != 0;
-              }
-            }
-            const float x_new = active ? (x_old - eps_hat * p.c1) / p.sqrt_alpha + p.sqrt_beta * z : x_old;
-            p.X[xi] = x_new;
-            if (p.step_i > 1) p.Unext[(size_t)row * p.ldu + col] = keep ? 2.f * x_new : 0.f;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          Cp[(size_t)row * p.ldc + col] = acc[a][b][r] + bias;
+        }
+      } else if (EPI == EPI_BIAS_TANH) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanhf(acc[a][b][r] + bias);
+        }
+      } else if (EPI == EPI_DPRELU) {
+        const float* __restrict__ auxp = p.aux;
+        float pre[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre[r] = auxp[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.ldaux + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          const float v = acc[a][b][r];
+          const bool pos = pre[r] > 0.f;
+          Cp[(size_t)row * p.ldc + col] = pos ? v : slopeE * v;
+          slope_sum += pos ? 0.f : v * pre[r];
+        }
+      } else if (EPI == EPI_SLAB) {
+        float* __restrict__ Sp = p.C + (size_t)blockIdx.z * p.slab_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          Sp[(size_t)row * p.ldc + col] = acc[a][b][r];
         }
       }
     }

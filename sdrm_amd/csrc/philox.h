@@ -35,14 +35,16 @@ __host__ __device__ inline U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
   return U4{c0, c1, c2, c3};
 }
 
-// Two standard normals from two 32-bit words (Box-Muller on 24-bit uniforms, accurate libm path).
+// Two standard normals from two 32-bit words: Box-Muller on 24-bit uniforms with the hardware
+// transcendentals (v_log_f32 = log2, v_sqrt_f32, v_sin/v_cos_f32 take their argument in turns).
+// Their ~1e-6 absolute error is irrelevant for noise and keeps the generator off the critical path
+// of the fused sampling epilogue; oracle/philox_ref.py mirrors the formula in numpy.
 __device__ inline void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
   const float u = (float)((a >> 8) + 1u) * 5.9604644775390625e-8f;  // (0,1]
-  const float v = (float)(b >> 8) * 5.9604644775390625e-8f;         // [0,1)
-  const float r = sqrtf(-2.0f * logf(u));
-  const float th = 6.283185307179586f * v;
-  n0 = r * cosf(th);
-  n1 = r * sinf(th);
+  const float v = (float)(b >> 8) * 5.9604644775390625e-8f;         // [0,1) turns
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // sqrt(-2 ln u)
+  n0 = r * __builtin_amdgcn_cosf(v);
+  n1 = r * __builtin_amdgcn_sinf(v);
 }
 
 // uniform integer in [0, n) from one word (multiply-high)

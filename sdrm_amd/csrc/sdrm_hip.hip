@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@ using namespace sdrm;
 
 namespace {
 
+constexpr int BM = 128, BN = 128;   // row padding granule / reference tile for split sizing
 constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
 constexpr int TARGET_BLOCKS = 512; // work-groups a wgrad launch aims for (2 per CU)
 constexpr int LOSS_BLOCKS = 256;
@@ -68,10 +70,10 @@ struct sdrm_engine {
 
 typedef sdrm_engine::SampleStateT SampleState;
 
-enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_FWD_OUT_REVERSE, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_COUNT };
+enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_COUNT };
 static const char* kProfNames[PC_COUNT] = {
     "gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
-    "gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)", "gemm_kernel<0,0,1,0,2> fwd out + reverse update",
+    "gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)",
     "gemm_kernel<0,1,0,0,3> dgrad (prelu' epilogue)", "gemm_kernel<1,1,0,1,4> wgrad (prelu-in, split-K slabs)",
     "gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)"};
 
@@ -104,9 +106,45 @@ const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
 struct Prof { sdrm_engine* e; int cls; double flops; };
 
-template <int LA, int LB, int XA, int XB, int EPI>
-hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0}) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+typedef TileCfg<128, 128, 2, 2> Cfg128x128;
+typedef TileCfg<64, 128, 2, 2> Cfg64x128;
+constexpr int N_TILE_CFGS = 2;
+const int kCfgBM[N_TILE_CFGS] = {128, 64};
+const int kCfgBN[N_TILE_CFGS] = {128, 128};
+int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override
+
+// Pick the tile shape whose busiest CU finishes first: blocks are dealt round-robin over 256 CUs, the
+// ones resident together on a CU share its matrix pipes, so time ~ ceil(blocks/256) * BM*BN / eff.
+int pick_cfg(int M, int N) {
+  if (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) return g_force_cfg;
+  const double eff[N_TILE_CFGS] = {1.0, 0.9};
+  int best = 0;
+  double best_cost = 1e300;
+  for (int c = 0; c < N_TILE_CFGS; ++c) {
+    const long blocks = (long)((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
+    const double cost = (double)((blocks + 255) / 256) * kCfgBM[c] * kCfgBN[c] / eff[c];
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+int gemm_blocks(int M, int N) {
+  const int c = pick_cfg(M, N);
+  return ((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
+}
+
+int max_gemm_blocks(int M, int N) {
+  int best = 0;
+  for (int c = 0; c < N_TILE_CFGS; ++c) {
+    const int b = ((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
+    if (b > best) best = b;
+  }
+  return best;
+}
+
+template <class Cfg, int LA, int LB, int XA, int XB, int EPI>
+hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr) {
+  const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
   a.tiles_n = tiles_n;
   a.nblocks = tiles_m * tiles_n;
   dim3 grid(a.nblocks, 1, splits);
@@ -120,10 +158,20 @@ hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Pr
     hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
     if (st0 != hipSuccess) return st0;
   }
-  hipLaunchKernelGGL((gemm_kernel<LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<Cfg, LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
   hipError_t rc = hipGetLastError();
   if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
   return rc;
+}
+
+template <int LA, int LB, int XA, int XB, int EPI>
+hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0},
+                       int cfg = -1) {
+  if (cfg < 0) cfg = pick_cfg(M, N);
+  switch (cfg) {
+    case 1: return launch_gemm_cfg<Cfg64x128, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    default: return launch_gemm_cfg<Cfg128x128, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+  }
 }
 
 // forward Linear: C[M,N] = act(xf(A)[M,K] * Wc[N,K]^T + bias)
@@ -165,7 +213,7 @@ hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int
 
 void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
   const int tiles = ((Nout + BM - 1) / BM) * ((Kin + BN - 1) / BN);
-  int want = (TARGET_BLOCKS + tiles - 1) / tiles;
+  int want = TARGET_BLOCKS / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
   if (max_by_rows < 1) max_by_rows = 1;
   S = want < 1 ? 1 : want;
@@ -184,6 +232,7 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
     j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
     j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
     j.inner = inner;
+    j.gdst = e->g + off; j.g_ld = flat_ld;
   };
   // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
   add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
@@ -199,6 +248,10 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
   }
   add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP);
   add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
+  tab.n_adam = n;
+  // finalize-only job: the one-hot columns of the layer-0 slabs -> dense dC0T[W][TP] for the emb backward
+  add(0, W, 0, 0, T + 1, e->slab0 + e->LP, e->K0, (size_t)e->WP * e->K0, S0, nullptr, 0);
+  tab.j[n - 1].gdst = e->dC0; tab.j[n - 1].g_ld = e->TP;
   tab.n = n;
 }
 
@@ -214,7 +267,7 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)std::sqrt(bc2);
   }
-  dim3 grid(128, tab.n);
+  dim3 grid(128, tab.n_adam);
   hipLaunchKernelGGL(k_adam, grid, dim3(256), 0, st, tab, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
@@ -295,8 +348,13 @@ void reverse_coeffs(const sdrm_engine* e, int i, float& c1, float& sa, float& sb
 // =================================================================================================
 extern "C" {
 
+int sdrm_debug_set_tile(int cfg) {
+  g_force_cfg = cfg;
+  return SDRM_OK;
+}
+
 const char* sdrm_build_info(void) {
-  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block 128x128x16, 4 waves x (2x2 tiles of 32x32); LDS 33 KB "
+  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tiles 128x128x16 / 64x128x16 chosen per launch, 4 waves, LDS "
          "double-buffered; split-K slabs for wgrad";
 }
 
@@ -309,6 +367,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (L < 1 || L > 4096 || W < 1 || W > 4096 || T < 2 || T > 1024 || H < 0 || H > 16 || max_rows < 1 ||
       max_rows > (1 << 22))
     return SDRM_ERR_SHAPE;
+  if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
@@ -350,10 +409,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     HIP_TRY(e, dalloc(&e->slabH, (size_t)H * S_MAX * e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->dbHs, (size_t)H * S_MAX * e->WP));
   }
-  e->alpha_part_stride = (int)((MP / BM) * ((e->WP + BN - 1) / BN));
+  e->alpha_part_stride = max_gemm_blocks((int)MP, e->WP);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
   HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
-  HIP_TRY(e, dalloc(&e->dC0, (size_t)n * W)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
+  HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows));
   int rc = upload_schedule(e, 1e-4f, 0.02f);
   if (rc) return rc;
@@ -508,7 +567,7 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   pick_splits(MP, e->WP, e->K0, S0, kc0);
   pick_splits(MP, e->WP, e->WP, SH, kcH);
   pick_splits(MP, e->LP, e->WP, SO, kcO);
-  const int dgrad_blocks = (MP / BM) * ((e->WP + BN - 1) / BN);
+  const int dgrad_blocks = gemm_blocks(MP, e->WP);  // every dgrad writes [MP,WP]: same tile shape, same count
   // output layer
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W,
                fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
@@ -530,22 +589,22 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
   HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
                                   Prof{e, PC_WGRAD_L0, fl0})));
+  JobTable tab;
+  build_jobs(e, tab, S0, SH, SO, dgrad_blocks);
+  hipLaunchKernelGGL(k_grad_finalize, dim3(512, tab.n), dim3(256), 0, st, tab);
+  HIP_TRY(e, hipGetLastError());
   EmbBwdArgs ea{};
-  ea.slab0 = e->slab0; ea.slab_stride = (size_t)e->WP * e->K0; ea.S = S0;
-  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dC0 = e->dC0; ea.dE = e->dE; ea.g = e->g;
+  ea.dC0T = e->dC0; ea.TP = e->TP;
+  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = e->g;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
-  ea.L = e->L; ea.W = e->W; ea.T = e->T; ea.LP = e->LP; ea.K0 = e->K0;
-  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(256), e->W * sizeof(float), st, ea);
+  ea.L = e->L; ea.W = e->W; ea.T = e->T;
+  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(128), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
   {
     const int items = e->W * e->T + e->T * e->T + e->T;
     hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
     HIP_TRY(e, hipGetLastError());
   }
-  JobTable tab;
-  build_jobs(e, tab, S0, SH, SO, dgrad_blocks);
-  hipLaunchKernelGGL(k_grad_finalize, dim3(128, tab.n), dim3(256), 0, st, tab, e->g);
-  HIP_TRY(e, hipGetLastError());
   if (grad && grad != e->g) HIP_TRY(e, hipMemcpyAsync(grad, e->g, e->P * 4, hipMemcpyDeviceToDevice, st));
   e->last_S = S0; e->last_dgrad_blocks = dgrad_blocks;
   return SDRM_OK;
@@ -689,19 +748,24 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     }
     int rc = hidden_forward(e, MP, n, st);
     if (rc) return rc;
-    GemmArgs a{};
-    a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
-    a.ldc = e->LP; a.rows_valid = n; a.Lreal = L;
-    a.X = e->X; a.Unext = e->U; a.ldu = e->K0;
-    a.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
-    a.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
-    a.Tj = s.multires ? e->Tj_dev : nullptr;
-    a.step_i = i; a.nd = s.nd;
-    reverse_coeffs(e, i, a.c1, a.sqrt_alpha, a.sqrt_beta);
-    a.rng_mode = s.mode; a.seed_lo = (uint32_t)s.seed; a.seed_hi = (uint32_t)(s.seed >> 32);
-    a.call_id = (uint32_t)s.call_id; a.row0 = s.row0;
-    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REVERSE>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
-                                                         Prof{e, PC_FWD_OUT_REVERSE, 2.0 * n * (double)e->L * e->W})));
+    {
+      GemmArgs a{};
+      a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+      a.rows_valid = MP; a.cols_valid = e->LP;
+      HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
+                                                        Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W})));
+    }
+    ReverseArgs ra{};
+    ra.X = e->X; ra.Y = e->Y; ra.U = e->U;
+    ra.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
+    ra.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
+    ra.Tj = s.multires ? e->Tj_dev : nullptr;
+    ra.n = n; ra.L = L; ra.LP = e->LP; ra.K0 = e->K0; ra.step_i = i; ra.nd = s.nd;
+    reverse_coeffs(e, i, ra.c1, ra.sqrt_alpha, ra.sqrt_beta);
+    ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
+    ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
+    hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, n), dim3(256), 0, st, ra);
+    HIP_TRY(e, hipGetLastError());
   }
   return SDRM_OK;
 }
