@@ -479,13 +479,42 @@ def fixture_fullsize(ref):
     np.savez_compressed(os.path.join(HERE, "fullsize.npz"), **out)
 
 
+def fixture_host(ref):
+    """Host-side contracts: state_dict key layout of SDRM for several H (aliased shared layer, Q1/a13),
+    and the metric / split helpers of utilities.py on small random data."""
+    import utilities as refutil  # the reference's own module (bottleneck stubbed by np.argpartition)
+    from scipy.sparse import csr_matrix
+    out = {}
+    for H in (0, 1, 2, 5):
+        net = ref.SDRM(6, 4, 6, H)
+        out[f"state_keys_H{H}"] = np.asarray(list(net.state_dict().keys()))
+        out[f"param_keys_H{H}"] = np.asarray([n for n, _ in net.named_parameters()])
+    rs = np.random.RandomState(9)
+    pred = rs.standard_normal((12, 40)).astype(np.float32)
+    held = csr_matrix((rs.random_sample((12, 40)) < 0.15).astype(np.float64))
+    dense_held = held.toarray()
+    dense_held[0, :] = 0          # a user with nothing held out (0/0 -> nan in both metrics)
+    held = csr_matrix(dense_held)
+    train = csr_matrix((rs.random_sample((12, 40)) < 0.2).astype(np.float64))
+    out["pred"], out["held"], out["train"] = pred, held.toarray(), train.toarray()
+    for k in (1, 5, 10):
+        with np.errstate(all="ignore"):
+            out[f"recall_{k}"] = refutil.recall_at_k_batch(pred.copy(), held, k=k)
+            out[f"ndcg_{k}"] = refutil.NDCG_binary_at_k_batch(pred.copy(), held, k=k)
+    out["masked"] = refutil.mask_training_examples(train, pred.copy())
+    data = csr_matrix((rs.random_sample((30, 25)) < 0.3).astype(np.float64))
+    tr, te = refutil.split_train_test_proportion_from_csr_matrix(data, batch_size=7, random_seed=123, test_prop=0.2)
+    out["split_in"], out["split_train"], out["split_test"] = data.toarray(), tr.toarray(), te.toarray()
+    np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize"]
+    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host"]
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
              "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
-             "fullsize": fixture_fullsize}
+             "fullsize": fixture_fullsize, "host": fixture_host}
     for w in which:
         table[w](ref)
         print("wrote", w)

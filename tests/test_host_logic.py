@@ -1,0 +1,104 @@
+"""Host-side logic that needs no GPU: C-ABI symbol export, parameter layout, metric/split helpers
+against vectors produced by the reference's own utilities.py, schedule/step-mix helpers."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy.sparse import csr_matrix
+
+from sdrm_amd import _lib, metrics, synth
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    """The library loads (no GPU needed) and exports exactly what include/sdrm_hip.h declares."""
+    header = open(os.path.join(REPO, "include", "sdrm_hip.h")).read()
+    declared = set(re.findall(r"\b(sdrm_[a-z_0-9]+)\s*\(", header))
+    declared -= {"sdrm_engine"}
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert b"gfx950" in lib.sdrm_build_info()
+
+
+def test_cabi_rejects_bad_arguments_without_a_gpu():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.sdrm_create(0, 8, 5, 1, 4, 0, ctypes.byref(h)) == -2          # SDRM_ERR_SHAPE
+    assert lib.sdrm_create(8, 8, 5, 1, 4, 0, None) == -1                     # SDRM_ERR_ARG
+    assert lib.sdrm_param_count(None) == -1
+    assert lib.sdrm_destroy(None) == -1
+
+
+@pytest.mark.parametrize("H", [0, 1, 2, 5])
+def test_parameter_layout_matches_reference(golden, H):
+    g = golden("host")
+    assert list(g[f"param_keys_H{H}"]) == synth.param_names(H)
+    from sdrm_amd.train_SDRM import SDRM
+    net = SDRM(6, 4, 6, H)
+    assert list(net.state_dict().keys()) == list(g[f"state_keys_H{H}"])
+    assert [n for n, _ in net.named_parameters()] == list(g[f"param_keys_H{H}"])
+    sd = net.state_dict()
+    for alias, target in synth.alias_keys(H).items():
+        assert sd[alias].data_ptr() == sd[target].data_ptr() or bool((sd[alias] == sd[target]).all())
+
+
+def test_param_count_formula():
+    # P = 2,145,054 for ML-100k/SVD, 380,504 for ML-1M/MLP, 17,384 for ADM/NeuMF
+    assert synth.param_count(830, 830, 83, 2) == 2_145_054
+    assert synth.param_count(340, 340, 78, 1) == 380_504
+    assert synth.param_count(40, 40, 93, 5) == 17_384
+
+
+def test_state_dict_roundtrip_cpu():
+    from sdrm_amd.train_SDRM import SDRM
+    a, b = SDRM(10, 5, 12, 3), SDRM(10, 5, 12, 3)
+    b.load_state_dict(a.state_dict())
+    for (_, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert bool((p == q).all())
+    bound = 1 / np.sqrt(10 + 5)
+    w0 = dict(a.named_parameters())["dnn.0.weight"]
+    assert float(w0.abs().max()) <= bound and float(dict(a.named_parameters())["dnn.1.weight"]) == 0.25
+
+
+def test_metrics_against_reference(golden):
+    g = golden("host")
+    held, train = csr_matrix(g["held"]), csr_matrix(g["train"])
+    for k in (1, 5, 10):
+        with np.errstate(all="ignore"):
+            np.testing.assert_allclose(metrics.recall_at_k_batch(g["pred"].copy(), held, k=k), g[f"recall_{k}"], rtol=1e-6)
+            np.testing.assert_allclose(metrics.NDCG_binary_at_k_batch(g["pred"].copy(), held, k=k), g[f"ndcg_{k}"], rtol=1e-6)
+    np.testing.assert_array_equal(metrics.mask_training_examples(train, g["pred"].copy()), g["masked"])
+
+
+def test_split_against_reference(golden):
+    g = golden("host")
+    tr, te = metrics.split_train_test_proportion_from_csr_matrix(csr_matrix(g["split_in"]), batch_size=7,
+                                                                 random_seed=123, test_prop=0.2)
+    np.testing.assert_array_equal(tr.toarray(), g["split_train"])
+    np.testing.assert_array_equal(te.toarray(), g["split_test"])
+
+
+def test_bench_step_mix():
+    import bench
+    n_train, cycle = 15, 93
+    kinds = [bench.is_train(k, n_train, cycle) for k in range(2 * cycle)]
+    assert sum(kinds[:cycle]) == n_train and sum(kinds) == 2 * n_train
+    gaps = np.diff(np.flatnonzero(kinds))
+    assert gaps.min() >= 6 and gaps.max() <= 7            # evenly spread
+    assert bench.train_flops(8192, 340, 78, 1) == pytest.approx(4.996e10, rel=1e-3)
+    assert bench.sample_flops(5429, 340, 78, 1) == pytest.approx(4.12e9, rel=1e-2)
+
+
+def test_shard_rows_partition():
+    from sdrm_amd.parallel import shard_rows
+    for n, w in [(8192, 8), (5429, 8), (7, 3), (3, 8)]:
+        spans = [shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and sum(s[1] for s in spans) == n
+        for (a, la), (b, _) in zip(spans, spans[1:]):
+            assert a + la == b
+        assert max(s[1] for s in spans) - min(s[1] for s in spans) <= 1

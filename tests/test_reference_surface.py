@@ -1,0 +1,92 @@
+"""The reference's call surface (`train_SDRM`, `sample_ddpm`, `SDRM`, `VAE`) driven the way main.py:126-185
+drives it, on a tiny synthetic dataset.  Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+from scipy.sparse import csr_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def make_feed(data, batch):
+    """What main.py:126-137 builds: a DataLoader over index batches yielding sparse COO tensors."""
+    feed = []
+    for lo in range(0, data.shape[0], batch):
+        coo = data[lo:lo + batch].tocoo()
+        x = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float32), coo.shape).cuda()
+        feed.append((x, x))
+    return feed
+
+
+def test_train_and_sample_like_main(tmp_path):
+    import sdrm_amd.train_SDRM as ts
+    rs = np.random.RandomState(0)
+    n_users, n_items = 96, 60
+    data = csr_matrix((rs.random_sample((n_users, n_items)) < 0.25).astype(np.float64))
+    valid = csr_matrix((rs.random_sample((40, n_items)) < 0.25).astype(np.float64))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    dl = make_feed(data, 40)                   # 40 + 40 + 16 rows: short last batch (Q15)
+    DIFF, vae = ts.train_SDRM(dl, N_ITEMS=n_items, VAE_HIDDEN=32, VAE_LATENT=20, VAE_BATCH_SIZE=32, VAE_LR=1e-3,
+                              DIFF_LATENT=20, N_HIDDEN_MLP_LAYERS=2, DIFF_LR=1e-3, DIFF_TRAINING_EPOCHS=3,
+                              TIMESTEPS=8, noise_divider=0.5, VAE_DIR_PATH=str(tmp_path / "vae"),
+                              TRAIN_PARTIAL_VALID_DATA=data, VALID_DATA=valid, OPTIMIZATION_OBJECTIVE="Recall@10")
+    assert isinstance(vae, torch.nn.Module) and vae.model_is_trained and not vae.training
+    assert np.isfinite(float(DIFF.last_loss.cpu()))
+    m, v, step = DIFF.engine().get_adam_state()
+    assert step == 3 * 3
+    assert ts.ab_t.shape[0] == 9 and float(ts.ab_t[0]) == 1.0
+    sparsity = 1 - data.nnz / (n_users * n_items)
+    for mode in ("random", None):
+        out = ts.sample_ddpm(n_users, DIFF, vae, 20, 0.5, timesteps=mode, n_timesteps=8)
+        arr = out.detach().cpu().numpy()
+        assert arr.shape == (n_users, n_items) and np.isfinite(arr).all()
+        binar = arr >= np.quantile(arr.flatten(), sparsity)          # main.py:177-180
+        assert abs(binar.mean() - (1 - sparsity)) < 0.02
+    # the module helpers work on the schedule left behind by train_SDRM (Q10)
+    x = torch.randn(5, 20, device="cuda")
+    t = torch.randint(1, 9, (5,), device="cuda")
+    xp = ts.perturb_input(x, t, torch.zeros_like(x))
+    assert torch.allclose(xp, ts.ab_t.sqrt()[t, None] * x)
+    y = DIFF.forward(x, t)
+    assert y.shape == (5, 20) and float(y.abs().max()) <= 1.0
+    assert not torch.equal(y, DIFF.forward(x, t))                       # dropout always on (Q2)
+    stepped = ts.denoise_add_noise(x, 3, y, 0)
+    assert stepped.shape == x.shape
+    loss = ts.score_matching_loss(DIFF, x, t, y, torch.randn_like(x), 0.1)
+    assert np.isfinite(float(loss))
+
+
+def test_state_dict_through_engine():
+    import sdrm_amd.train_SDRM as ts
+    a = ts.SDRM(16, 6, 24, 3)
+    a.engine(4)
+    sd = a.state_dict()
+    assert sd["dnn.4.weight"].shape == (24, 24) and torch.equal(sd["dnn.4.weight"], sd["dnn.2.weight"])
+    b = ts.SDRM(16, 6, 24, 3)
+    b.load_state_dict(sd)
+    b.engine(4)
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.cpu(), q.cpu()), n
+    # growing the engine keeps parameters and optimiser state
+    x = torch.randn(4, 16, device="cuda")
+    a.engine(4).train_step(x, 1e-3, seed=1, step=0)
+    before = a.engine().get_params().clone()
+    a.engine(64)
+    assert torch.equal(before, a.engine().get_params()) and a.engine().get_adam_state()[2] == 1
+
+
+def test_cache_latents_matches_per_batch_encoding(tmp_path):
+    """encoding the feed once gives the same trained eps-net as encoding per batch."""
+    import sdrm_amd.train_SDRM as ts
+    rs = np.random.RandomState(1)
+    data = csr_matrix((rs.random_sample((50, 30)) < 0.3).astype(np.float64))
+    vae = ts.VAE(30, 16, 10).cuda()
+    vae.model_is_trained = True
+    outs = []
+    for cache in (False, True):
+        torch.manual_seed(3)
+        D, _ = ts.train_SDRM(make_feed(data, 25), 30, 16, 10, 25, 1e-3, 10, 1, 1e-3, 2, 5, 1.0, str(tmp_path), data, data,
+                             "Recall@10", variational_ae=vae, cache_latents=cache)
+        outs.append(D.engine().get_params().cpu())
+    assert torch.allclose(outs[0], outs[1], rtol=0, atol=0)
