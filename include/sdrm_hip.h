@@ -178,8 +178,11 @@ const char* sdrm_build_info(void);
 int sdrm_debug_set_tile(int cfg);
 /* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),
  * A^T * B (variant 2, A is [K,M], B is [K,N]) through the same MFMA kernel the engine uses.  All
- * dims must be multiples of 32 and M (variant 0/1) resp. K (variant 2) a multiple of 128. */
+ * dims must be multiples of 32.  Stages the operands in zero-padded scratch and synchronises. */
 int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+/* Same kernel timed: `reps` launches on zero-filled scratch operands, mean microseconds per launch by
+ * HIP events on `stream` (tools/gemm_tune.py). */
+int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_out, void* stream);
 
 #ifdef __cplusplus
 }

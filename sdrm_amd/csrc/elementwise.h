@@ -148,6 +148,17 @@ struct EmbTabArgs {
   int L, W, T, LP, WP, K0;
 };
 
+__device__ __forceinline__ float dot_unrolled(const float* __restrict__ x, const float* __restrict__ y, int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < n; i += 4) {   // four independent load pairs in flight
+    s0 = fmaf(x[i], y[i], s0); s1 = fmaf(x[i + 1], y[i + 1], s1);
+    s2 = fmaf(x[i + 2], y[i + 2], s2); s3 = fmaf(x[i + 3], y[i + 3], s3);
+  }
+  for (; i < n; ++i) s0 = fmaf(x[i], y[i], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
 __global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
   extern __shared__ float sh[];  // [2*T]: temb row, E row
   const int t = blockIdx.x;
@@ -156,20 +167,14 @@ __global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
   for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
   __syncthreads();
   for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
-    float s = a.be[j];
-    const float* wr = a.We + (size_t)j * a.T;
-    for (int i = 0; i < a.T; ++i) s = fmaf(wr[i], tr[i], s);
+    const float s = a.be[j] + dot_unrolled(a.We + (size_t)j * a.T, tr, a.T);
     er[j] = s;
     a.Etab[(size_t)t * a.T + j] = s;
   }
   __syncthreads();
   const int ldw = a.L + a.T;
   for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
-    float s = 0.f;
-    if (w < a.W) {
-      const float* wr = a.W0 + (size_t)w * ldw + a.L;
-      for (int j = 0; j < a.T; ++j) s = fmaf(wr[j], er[j], s);
-    }
+    const float s = (w < a.W) ? dot_unrolled(a.W0 + (size_t)w * ldw + a.L, er, a.T) : 0.f;
     a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
     if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : 0.f;
   }
@@ -195,19 +200,45 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return s;
 }
 
+// four consecutive columns of an unpadded [rows, L] matrix (vector load when rows are 16-B aligned)
+__device__ __forceinline__ float4 load4_unpadded(const float* __restrict__ x, int r, int c, int L) {
+  const float* p = x + (size_t)r * L + c;
+  if ((L & 3) == 0) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < L) v.x = p[0];
+  if (c + 1 < L) v.y = p[1];
+  if (c + 2 < L) v.z = p[2];
+  if (c + 3 < L) v.w = p[3];
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_loss_partials(const LossArgs a) {
   __shared__ double sh[4];
   double sD = 0, sC = 0, sR = 0, sR2 = 0;
-  const size_t total = (size_t)a.B * a.L;
+  const int QP = a.LP >> 2;
+  const size_t total = (size_t)a.B * QP;
   const size_t BLP = (size_t)a.B * a.LP;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / a.L), c = (int)(i - (size_t)r * a.L);
+    const int r = (int)(i / QP), c = 4 * (int)(i - (size_t)r * QP);
+    if (c >= a.L) continue;
     const size_t yi = (size_t)r * a.LP + c;
-    const float P = a.Y[yi], S = a.Y[BLP + yi], Q = a.Y[2 * BLP + yi];
-    const float R = P - a.x0[i];
-    const float D = (Q - S) / MU2 - R;
-    const float RS = R - S;
-    sD += (double)D * D; sC += (double)RS * RS; sR += R; sR2 += (double)R * R;
+    const float4 P = *reinterpret_cast<const float4*>(a.Y + yi);
+    const float4 S = *reinterpret_cast<const float4*>(a.Y + BLP + yi);
+    const float4 Q = *reinterpret_cast<const float4*>(a.Y + 2 * BLP + yi);
+    const float4 X = load4_unpadded(a.x0, r, c, a.L);
+    const float p_[4] = {P.x, P.y, P.z, P.w}, s_[4] = {S.x, S.y, S.z, S.w}, q_[4] = {Q.x, Q.y, Q.z, Q.w},
+                x_[4] = {X.x, X.y, X.z, X.w};
+    float fD = 0.f, fC = 0.f, fR = 0.f, fR2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < a.L) {
+        const float R = p_[j] - x_[j];
+        const float D = (q_[j] - s_[j]) / MU2 - R;
+        const float RS = R - s_[j];
+        fD += D * D; fC += RS * RS; fR += R; fR2 += R * R;
+      }
+    }
+    sD += fD; sC += fC; sR += fR; sR2 += fR2;
   }
   const double tD = block_sum(sD, sh), tC = block_sum(sC, sh), tR = block_sum(sR, sh), tR2 = block_sum(sR2, sh);
   if (threadIdx.x == 0) {
@@ -235,12 +266,15 @@ struct SeedArgs {
 };
 
 __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
-  const int r = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.LP) return;
+  const int QP = a.LP >> 2;
+  const size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int r = (int)(flat / QP);
+  const int c = 4 * (int)(flat - (size_t)r * QP);
+  if (r >= a.B + (a.MP - 3 * a.B)) return;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r >= a.B) {
     const int row = 3 * a.B + (r - a.B);
-    if (row < a.MP) a.dY[(size_t)row * a.LP + c] = 0.f;
+    if (row < a.MP) *reinterpret_cast<float4*>(a.dY + (size_t)row * a.LP + c) = zero;
     return;
   }
   const double N = a.sums[4];
@@ -251,21 +285,35 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   if (r == 0 && c == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);
   const size_t BLP = (size_t)a.B * a.LP;
   const size_t yi = (size_t)r * a.LP + c;
-  float gP = 0.f, gS = 0.f, gQ = 0.f;
+  float gP[4] = {0.f, 0.f, 0.f, 0.f}, gS[4] = {0.f, 0.f, 0.f, 0.f}, gQ[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < a.L) {
     const float cD = (float)(2.0 * k / N);
     const float cV = (float)(-(0.5 * (A + C) / (den * den)) * 2.0 / (N - 1.0));
-    const float P = a.Y[yi], S = a.Y[BLP + yi], Q = a.Y[2 * BLP + yi];
-    const float R = P - a.x0[(size_t)r * a.L + c];
-    const float D = (Q - S) / MU2 - R;
-    const float gD = cD * D;
-    const float gC = cD * (R - S);
-    const float gV = cV * (R - (float)Rbar);
-    gP = (-gD + gC + gV) * (1.f - P * P);
-    gQ = (gD / MU2) * (1.f - Q * Q);
-    gS = (-gD / MU2 - gC) * (1.f - S * S);
+    const float rbar = (float)Rbar;
+    const float4 P4 = *reinterpret_cast<const float4*>(a.Y + yi);
+    const float4 S4 = *reinterpret_cast<const float4*>(a.Y + BLP + yi);
+    const float4 Q4 = *reinterpret_cast<const float4*>(a.Y + 2 * BLP + yi);
+    const float4 X4 = load4_unpadded(a.x0, r, c, a.L);
+    const float p_[4] = {P4.x, P4.y, P4.z, P4.w}, s_[4] = {S4.x, S4.y, S4.z, S4.w}, q_[4] = {Q4.x, Q4.y, Q4.z, Q4.w},
+                x_[4] = {X4.x, X4.y, X4.z, X4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (c + j < a.L) {
+        const float P = p_[j], S = s_[j], Q = q_[j];
+        const float R = P - x_[j];
+        const float D = (Q - S) / MU2 - R;
+        const float gD = cD * D;
+        const float gC = cD * (R - S);
+        const float gV = cV * (R - rbar);
+        gP[j] = (-gD + gC + gV) * (1.f - P * P);
+        gQ[j] = (gD / MU2) * (1.f - Q * Q);
+        gS[j] = (-gD / MU2 - gC) * (1.f - S * S);
+      }
+    }
   }
-  a.dY[yi] = gP; a.dY[BLP + yi] = gS; a.dY[2 * BLP + yi] = gQ;
+  *reinterpret_cast<float4*>(a.dY + yi) = make_float4(gP[0], gP[1], gP[2], gP[3]);
+  *reinterpret_cast<float4*>(a.dY + BLP + yi) = make_float4(gS[0], gS[1], gS[2], gS[3]);
+  *reinterpret_cast<float4*>(a.dY + 2 * BLP + yi) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -281,40 +329,68 @@ struct EmbBwdArgs {
   int L, W, T;
 };
 
-__global__ __launch_bounds__(128) void k_emb_bwd1(const EmbBwdArgs a) {
+// 1024 threads = 16 w-slices x 64 j-lanes; the slices meet in LDS.
+__global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
+  __shared__ float red[16][64];
   const int t = blockIdx.x;
+  const int jj = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int ldw = a.L + a.T;
-  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
+  const int wlo = (a.W * part) / 16, whi = (a.W * (part + 1)) / 16;
+  for (int j0 = 0; j0 < a.T; j0 += 64) {
+    const int j = j0 + jj;
     float s0 = 0.f, s1 = 0.f;
-    int w = 0;
-    for (; w + 1 < a.W; w += 2) {
-      s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
-      s1 = fmaf(a.dC0T[(size_t)(w + 1) * a.TP + t], a.W0[(size_t)(w + 1) * ldw + a.L + j], s1);
+    if (j < a.T) {
+      int w = wlo;
+      for (; w + 1 < whi; w += 2) {
+        s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
+        s1 = fmaf(a.dC0T[(size_t)(w + 1) * a.TP + t], a.W0[(size_t)(w + 1) * ldw + a.L + j], s1);
+      }
+      if (w < whi) s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
     }
-    if (w < a.W) s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
-    a.dE[(size_t)t * a.T + j] = s0 + s1;
+    __syncthreads();
+    red[part][jj] = s0 + s1;
+    __syncthreads();
+    if (part == 0 && j < a.T) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[q][jj];
+      a.dE[(size_t)t * a.T + j] = s;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
   const int n1 = a.W * a.T, n2 = a.T * a.T, n3 = a.T;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nt = a.T + 1;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n1) {
     const int w = i / a.T, j = i - w * a.T;
     const float* dc = a.dC0T + (size_t)w * a.TP;
-    float s = 0.f;
-    for (int t = 0; t <= a.T; ++t) s = fmaf(dc[t], a.Etab[(size_t)t * a.T + j], s);
-    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = s;
+    const float* ec = a.Etab + j;
+    int t = 0;
+    for (; t + 3 < nt; t += 4) {
+      s0 = fmaf(dc[t], ec[(size_t)t * a.T], s0); s1 = fmaf(dc[t + 1], ec[(size_t)(t + 1) * a.T], s1);
+      s2 = fmaf(dc[t + 2], ec[(size_t)(t + 2) * a.T], s2); s3 = fmaf(dc[t + 3], ec[(size_t)(t + 3) * a.T], s3);
+    }
+    for (; t < nt; ++t) s0 = fmaf(dc[t], ec[(size_t)t * a.T], s0);
+    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = (s0 + s1) + (s2 + s3);
   } else if (i < n1 + n2) {
     const int k = i - n1;
     const int j = k / a.T, ii = k - j * a.T;
-    float s = 0.f;
-    for (int t = 0; t <= a.T; ++t) s = fmaf(a.dE[(size_t)t * a.T + j], a.temb[(size_t)t * a.T + ii], s);
-    a.g[a.off_we + k] = s;
+    const float* de = a.dE + j;
+    const float* te = a.temb + ii;
+    int t = 0;
+    for (; t + 3 < nt; t += 4) {
+      s0 = fmaf(de[(size_t)t * a.T], te[(size_t)t * a.T], s0); s1 = fmaf(de[(size_t)(t + 1) * a.T], te[(size_t)(t + 1) * a.T], s1);
+      s2 = fmaf(de[(size_t)(t + 2) * a.T], te[(size_t)(t + 2) * a.T], s2); s3 = fmaf(de[(size_t)(t + 3) * a.T], te[(size_t)(t + 3) * a.T], s3);
+    }
+    for (; t < nt; ++t) s0 = fmaf(de[(size_t)t * a.T], te[(size_t)t * a.T], s0);
+    a.g[a.off_we + k] = (s0 + s1) + (s2 + s3);
   } else if (i < n1 + n2 + n3) {
     const int j = i - n1 - n2;
     float s = 0.f;
-    for (int t = 0; t <= a.T; ++t) s += a.dE[(size_t)t * a.T + j];
+    for (int t = 0; t < nt; ++t) s += a.dE[(size_t)t * a.T + j];
     a.g[a.off_be + j] = s;
   }
 }
@@ -344,11 +420,12 @@ __global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (jb.inner == 1) {
       int k = 0;
-      for (; k + 3 < jb.nslabs; k += 4) {   // four independent loads in flight per thread
-        a0 += s[(size_t)k * jb.slab_stride];
-        a1 += s[(size_t)(k + 1) * jb.slab_stride];
-        a2 += s[(size_t)(k + 2) * jb.slab_stride];
-        a3 += s[(size_t)(k + 3) * jb.slab_stride];
+      for (; k + 7 < jb.nslabs; k += 8) {   // eight independent loads in flight per thread
+        const float v0 = s[(size_t)k * jb.slab_stride], v1 = s[(size_t)(k + 1) * jb.slab_stride];
+        const float v2 = s[(size_t)(k + 2) * jb.slab_stride], v3 = s[(size_t)(k + 3) * jb.slab_stride];
+        const float v4 = s[(size_t)(k + 4) * jb.slab_stride], v5 = s[(size_t)(k + 5) * jb.slab_stride];
+        const float v6 = s[(size_t)(k + 6) * jb.slab_stride], v7 = s[(size_t)(k + 7) * jb.slab_stride];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a0 += v4; a1 += v5; a2 += v6; a3 += v7;
       }
       for (; k < jb.nslabs; ++k) a0 += s[(size_t)k * jb.slab_stride];
     } else {

@@ -40,9 +40,10 @@ enum : int {
 
 constexpr int BK = 16, NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_>
+template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int MINW = MINW_;   // waves per SIMD the register allocator must leave room for
   static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;   // MFMA tiles per wave
   static constexpr int LDA = BM_ + 4, LDB = BN_ + 4;               // LDS row strides (floats)
   static constexpr int STAGE = BK * (LDA + LDB);                   // floats per pipeline stage
@@ -71,46 +72,49 @@ struct GemmArgs {
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
 
-// Global -> registers for one operand tile (ROWS x BK elements, ROWS = BM or BN).
-template <int LOAD, int XF, int ROWS>
-__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int i0, int lim, int k0,
-                                          float slope, float4 (&r)[ROWS * BK / 4 / NTHREADS], int tid) {
+// Global -> registers for one operand tile (ROWS x BK elements, ROWS = BM or BN).  No bounds checks:
+// every operand buffer is allocated with its tiled extent (rows rounded up to the tile, plus a slack
+// tail), rows/cols beyond the matrix feed only output rows/cols the epilogue discards, and weight pad
+// rows are zero.  Branch-free loads are what lets the compiler keep them in flight behind counted waits.
+template <int LOAD, int ROWS>
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int i0, int k0,
+                                          float4 (&r)[ROWS * BK / 4 / NTHREADS], int tid) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (LOAD == LD_KCONTIG) {
       const int i = f >> 2, kq = f & 3;
-      if (i0 + i < lim) v = *reinterpret_cast<const float4*>(src + (size_t)(i0 + i) * ld + k0 + 4 * kq);
+      r[s] = *reinterpret_cast<const float4*>(src + (size_t)(i0 + i) * ld + k0 + 4 * kq);
     } else {
       constexpr int VPR = ROWS / 4;  // float4 per k-row
       const int k = f / VPR, iq = f - k * VPR;
-      if (i0 + 4 * iq < lim) v = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + i0 + 4 * iq);
+      r[s] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + i0 + 4 * iq);
     }
-    if (XF == XF_PRELU) {
-      v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope); v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
-    }
-    r[s] = v;
   }
 }
 
-// Registers -> LDS (k-major, row stride LD).
-template <int LOAD, int ROWS, int LD>
+// Registers -> LDS (k-major, row stride LD).  The operand transform (PReLU of stored pre-activations)
+// is applied here, not at load time, so the global loads stay in flight across two K-steps.
+template <int LOAD, int XF, int ROWS, int LD>
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4 (&r)[ROWS * BK / 4 / NTHREADS],
-                                           int tid) {
+                                           float slope, int tid) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
+    float4 v = r[s];
+    if (XF == XF_PRELU) {
+      v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope); v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
+    }
     if (LOAD == LD_KCONTIG) {
       const int i = f >> 2, kq = f & 3;
       float* d = dst + (4 * kq) * LD + i;
-      d[0] = r[s].x; d[LD] = r[s].y; d[2 * LD] = r[s].z; d[3 * LD] = r[s].w;
+      d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
     } else {
       constexpr int VPR = ROWS / 4;
       const int k = f / VPR, iq = f - k * VPR;
-      *reinterpret_cast<float4*>(dst + k * LD + 4 * iq) = r[s];
+      *reinterpret_cast<float4*>(dst + k * LD + 4 * iq) = v;
     }
   }
 }
@@ -124,7 +128,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }
 
 template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArgs p) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, TM = Cfg::TM, TN = Cfg::TN, LDA = Cfg::LDA, LDB = Cfg::LDB;
   constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
   static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
@@ -152,30 +156,29 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 ra[NVA], rb[NVB];
+  // Two register sets hold the K-steps i+1 and i+2 while step i is multiplied out of LDS: every global
+  // load has two full K-steps to land (an HBM round trip is longer than one 16-deep step of MFMAs).
+  float4 ra0[NVA], rb0[NVB], ra1[NVA], rb1[NVB];
   float dbsum = 0.f;
   const bool do_dbias = (EPI == EPI_SLAB) && (p.dbias != nullptr) && (tile_n == 0) && (tid < BM);
-
-  int stage = 0;
-  if (kb < ke) {
-    load_tile<LOADA, XFA, BM>(p.A, p.lda, m0, p.limA, kb, slopeA, ra, tid);
-    load_tile<LOADB, XFB, BN>(p.B, p.ldb, n0, p.limB, kb, slopeB, rb, tid);
-    store_tile<LOADA, BM, LDA>(smem, ra, tid);
-    store_tile<LOADB, BN, LDB>(smem + BK * LDA, rb, tid);
-  }
-  __syncthreads();
+  const int nt = (ke - kb + BK - 1) / BK;   // K-steps of this block (>= 0)
 
   const int aoff = lhi * LDA + wm * (BM / Cfg::WM) + l31;
   const int boff = lhi * LDB + wn * (BN / Cfg::WN) + l31;
 
-  for (int kt = kb; kt < ke; kt += BK) {
+  auto ld = [&](float4 (&xa)[NVA], float4 (&xb)[NVB], int i) {
+    const int k0 = kb + min(i, nt - 1) * BK;   // past the end: re-read the last K-step (never consumed)
+    load_tile<LOADA, BM>(p.A, p.lda, m0, k0, xa, tid);
+    load_tile<LOADB, BN>(p.B, p.ldb, n0, k0, xb, tid);
+  };
+  auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
+    float* An = smem + stage * Cfg::STAGE;
+    store_tile<LOADA, XFA, BM, LDA>(An, xa, slopeA, tid);
+    store_tile<LOADB, XFB, BN, LDB>(An + BK * LDA, xb, slopeB, tid);
+  };
+  auto compute = [&](int stage) {
     const float* As = smem + stage * Cfg::STAGE;
     const float* Bs = As + BK * LDA;
-    const bool more = (kt + BK) < ke;
-    if (more) {
-      load_tile<LOADA, XFA, BM>(p.A, p.lda, m0, p.limA, kt + BK, slopeA, ra, tid);
-      load_tile<LOADB, XFB, BN>(p.B, p.ldb, n0, p.limB, kt + BK, slopeB, rb, tid);
-    }
     // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
     // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
     float af[2][TM], bf[2][TN];
@@ -204,13 +207,26 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) dbsum += As[k * LDA + tid];
     }
-    if (more) {
-      float* An = smem + (stage ^ 1) * Cfg::STAGE;
-      store_tile<LOADA, BM, LDA>(An, ra, tid);
-      store_tile<LOADB, BN, LDB>(An + BK * LDA, rb, tid);
-    }
+  };
+
+  if (nt > 0) {
+    ld(ra0, rb0, 0);
+    st(ra0, rb0, 0);
+    ld(ra0, rb0, 1);
+    ld(ra1, rb1, 2);
     __syncthreads();
-    stage ^= 1;
+    int i = 0;
+    for (; i + 1 < nt; i += 2) {
+      st(ra0, rb0, 1);          // set 0 holds K-step i+1
+      ld(ra0, rb0, i + 3);
+      compute(0);
+      __syncthreads();
+      st(ra1, rb1, 0);          // set 1 holds K-step i+2
+      ld(ra1, rb1, i + 4);
+      compute(1);
+      __syncthreads();
+    }
+    if (i < nt) compute(0);     // odd count: the last K-step already sits in stage 0
   }
 
   // ------------------------------------------------------------------ epilogue
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int tm0 = m0 + wm * (BM / Cfg::WM) + a * 32, tn0 = n0 + wn * (BN / Cfg::WN) + b * 32;
+      __builtin_amdgcn_sched_barrier(0);   // one tile's addresses live at a time (keeps the kernel at <=128 VGPRs)
       if (tm0 >= p.limA || tn0 >= p.limB) continue;  // wave-uniform: tile entirely outside the matrix
       const int col = tn0 + l31;
       const int rbase = tm0 + 4 * lhi;

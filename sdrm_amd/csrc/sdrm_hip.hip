@@ -93,11 +93,13 @@ int fail(sdrm_engine* e, int code, const std::string& msg) {
   return code;
 }
 
+constexpr size_t SLACK = 4096;  // elements of zeroed tail on every buffer: unguarded tile loads may run past a matrix
+
 template <typename Tp>
 hipError_t dalloc(Tp** p, size_t n) {
-  hipError_t st = hipMalloc((void**)p, n * sizeof(Tp));
+  hipError_t st = hipMalloc((void**)p, (n + SLACK) * sizeof(Tp));
   if (st != hipSuccess) return st;
-  return hipMemset(*p, 0, n * sizeof(Tp));
+  return hipMemset(*p, 0, (n + SLACK) * sizeof(Tp));
 }
 
 float* pre_buf(sdrm_engine* e, int k) { return e->pre + (size_t)k * e->MPmax * e->WP; }
@@ -394,9 +396,9 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   const int n = T + 1;
   HIP_TRY(e, dalloc(&e->p, e->P)); HIP_TRY(e, dalloc(&e->m, e->P));
   HIP_TRY(e, dalloc(&e->v, e->P)); HIP_TRY(e, dalloc(&e->g, e->P));
-  HIP_TRY(e, dalloc(&e->W0c, (size_t)e->WP * e->K0)); HIP_TRY(e, dalloc(&e->b0c, e->WP));
-  HIP_TRY(e, dalloc(&e->Whc, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
-  HIP_TRY(e, dalloc(&e->Woc, (size_t)e->LP * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
+  HIP_TRY(e, dalloc(&e->W0c, (size_t)round_up(e->WP, 128) * e->K0)); HIP_TRY(e, dalloc(&e->b0c, e->WP));
+  HIP_TRY(e, dalloc(&e->Whc, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
+  HIP_TRY(e, dalloc(&e->Woc, (size_t)round_up(e->LP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
@@ -559,7 +561,7 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
   {
-    dim3 grid((e->LP + 255) / 256, B + (MP - 3 * B));
+    dim3 grid((unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256));
     hipLaunchKernelGGL(k_loss_seed, grid, dim3(256), 0, st, sa);
     HIP_TRY(e, hipGetLastError());
   }
@@ -598,7 +600,7 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = e->g;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
-  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(128), 0, st, ea);
+  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(1024), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
   {
     const int items = e->W * e->T + e->T * e->T + e->T;
@@ -848,26 +850,68 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 // ---------------------------------------------------------------------------------------------
 int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
   if (!A || !B || !C) return SDRM_ERR_ARG;
-  if (M % 32 || N % 32 || K % 32) return SDRM_ERR_SHAPE;
+  if (M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2) return SDRM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
+  // The kernel reads whole tiles without bounds checks, so stage the caller's matrices in zero-padded
+  // scratch (test hook only: allocates and synchronises).
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
+  const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;     // A as stored: [M,K] or [K,M]
+  const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;     // B as stored: [N,K] or [K,N]
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  if (dalloc(&dA, (size_t)ar * ac) != hipSuccess || dalloc(&dB, (size_t)br * bc) != hipSuccess ||
+      dalloc(&dC, (size_t)Mp * Np) != hipSuccess)
+    return SDRM_ERR_NOMEM;
+  const int a_rows = variant == 2 ? K : M, a_cols = variant == 2 ? M : K;
+  const int b_rows = variant == 0 ? N : K, b_cols = variant == 0 ? K : N;
+  hipError_t rc = hipMemcpy2DAsync(dA, (size_t)ac * 4, A, (size_t)a_cols * 4, (size_t)a_cols * 4, a_rows, hipMemcpyDeviceToDevice, st);
+  if (rc == hipSuccess)
+    rc = hipMemcpy2DAsync(dB, (size_t)bc * 4, B, (size_t)b_cols * 4, (size_t)b_cols * 4, b_rows, hipMemcpyDeviceToDevice, st);
   GemmArgs a{};
-  a.C = C; a.ldc = N; a.K = K; a.kchunk = K;
-  hipError_t rc;
-  if (variant == 0) {
-    if (M % BM) return SDRM_ERR_SHAPE;
-    a.A = A; a.lda = K; a.limA = M; a.B = B; a.ldb = K; a.limB = N;
-    rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-  } else if (variant == 1) {
-    if (M % BM) return SDRM_ERR_SHAPE;
-    a.A = A; a.lda = K; a.limA = M; a.B = B; a.ldb = N; a.limB = N;
-    rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-  } else if (variant == 2) {
-    if (K % BM) return SDRM_ERR_SHAPE;
-    a.A = A; a.lda = M; a.limA = M; a.B = B; a.ldb = N; a.limB = N;
-    rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-  } else {
-    return SDRM_ERR_ARG;
+  a.C = dC; a.ldc = Np; a.K = K; a.kchunk = K;
+  a.A = dA; a.lda = ac; a.limA = M; a.B = dB; a.ldb = bc; a.limB = N;
+  if (rc == hipSuccess) {
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
   }
+  if (rc == hipSuccess)
+    rc = hipMemcpy2DAsync(C, (size_t)N * 4, dC, (size_t)Np * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  return rc == hipSuccess ? SDRM_OK : SDRM_ERR_HIP;
+}
+
+/* Timing variant of the hook for tools/gemm_tune.py: same kernel, `reps` launches on pre-padded scratch,
+ * returns the mean microseconds per launch measured with HIP events on `stream`. */
+int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_out, void* stream) {
+  if (!us_out || reps < 1 || M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2) return SDRM_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
+  const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
+  const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  if (dalloc(&dA, (size_t)ar * ac) != hipSuccess || dalloc(&dB, (size_t)br * bc) != hipSuccess ||
+      dalloc(&dC, (size_t)Mp * Np) != hipSuccess)
+    return SDRM_ERR_NOMEM;
+  GemmArgs a{};
+  a.C = dC; a.ldc = Np; a.K = K; a.kchunk = K;
+  a.A = dA; a.lda = ac; a.limA = M; a.B = dB; a.ldb = bc; a.limB = N;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipError_t rc = hipSuccess;
+  for (int i = 0; i < reps + 3 && rc == hipSuccess; ++i) {
+    if (i == 3) (void)hipEventRecord(e0, st);
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+  }
+  (void)hipEventRecord(e1, st);
+  if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+  float ms = 0.f;
+  if (rc == hipSuccess) rc = hipEventElapsedTime(&ms, e0, e1);
+  *us_out = ms * 1e3f / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
   return rc == hipSuccess ? SDRM_OK : SDRM_ERR_HIP;
 }
 
