@@ -174,7 +174,8 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
-/* Forces the GEMM tile shape (0 = 128x128, 1 = 64x128, -1 = automatic); also env SDRM_TILE.  Tuning aid. */
+/* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, -1 = default);
+ * also env SDRM_TILE.  Tuning aid. */
 int sdrm_debug_set_tile(int cfg);
 /* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),
  * A^T * B (variant 2, A is [K,M], B is [K,N]) through the same MFMA kernel the engine uses.  All

@@ -410,29 +410,54 @@ struct Job {
 constexpr int MAX_JOBS = 12;
 struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
 
+// Four lanes share one group of 4 consecutive padded columns: each sums a quarter of the slabs with
+// 16-byte loads (4 in flight), then the quarters meet through the wave.  Keeps ~8 MB of loads in flight
+// chip-wide, which is what an HBM-bound reduction of S slabs needs.
 __global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab) {
   const Job& jb = tab.j[blockIdx.y];
   if (jb.src == nullptr) return;
-  const int64_t total = (int64_t)jb.rows * jb.ncols;
+  if (jb.inner > 1) {   // scalar job (slope partials): one wave, fixed order
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    float a = 0.f;
+    const int total = jb.nslabs * jb.inner;
+    for (int i = threadIdx.x; i < total; i += 64) a += jb.src[(size_t)(i / jb.inner) * jb.slab_stride + (i % jb.inner)];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (threadIdx.x == 0) jb.gdst[0] = a;
+    return;
+  }
+  const int qpr = (jb.ncols + 3) >> 2;                      // column quads per row
+  const int64_t total = (int64_t)jb.rows * qpr * 4;         // x4 slab quarters
+  const int part = threadIdx.x & 3;
+  const int kb = (jb.nslabs * part) >> 2, ke = (jb.nslabs * (part + 1)) >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / jb.ncols), c = (int)(i - (int64_t)r * jb.ncols);
+    const int64_t quad = i >> 2;
+    const int r = (int)(quad / qpr), c = 4 * (int)(quad - (int64_t)r * qpr);
     const float* s = jb.src + (size_t)r * jb.src_ld + c;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (jb.inner == 1) {
-      int k = 0;
-      for (; k + 7 < jb.nslabs; k += 8) {   // eight independent loads in flight per thread
-        const float v0 = s[(size_t)k * jb.slab_stride], v1 = s[(size_t)(k + 1) * jb.slab_stride];
-        const float v2 = s[(size_t)(k + 2) * jb.slab_stride], v3 = s[(size_t)(k + 3) * jb.slab_stride];
-        const float v4 = s[(size_t)(k + 4) * jb.slab_stride], v5 = s[(size_t)(k + 5) * jb.slab_stride];
-        const float v6 = s[(size_t)(k + 6) * jb.slab_stride], v7 = s[(size_t)(k + 7) * jb.slab_stride];
-        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a0 += v4; a1 += v5; a2 += v6; a3 += v7;
-      }
-      for (; k < jb.nslabs; ++k) a0 += s[(size_t)k * jb.slab_stride];
-    } else {
-      for (int k = 0; k < jb.nslabs; ++k)
-        for (int q = 0; q < jb.inner; ++q) a0 += s[(size_t)k * jb.slab_stride + q];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    int k = kb;
+    for (; k + 1 < ke; k += 2) {
+      const float4 v0 = *reinterpret_cast<const float4*>(s + (size_t)k * jb.slab_stride);
+      const float4 v1 = *reinterpret_cast<const float4*>(s + (size_t)(k + 1) * jb.slab_stride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
     }
-    jb.gdst[(int64_t)r * jb.g_ld + c] = (a0 + a1) + (a2 + a3);
+    if (k < ke) {
+      const float4 v0 = *reinterpret_cast<const float4*>(s + (size_t)k * jb.slab_stride);
+      a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+    }
+    float v[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] += __shfl_xor(v[j], 1, 64);
+      v[j] += __shfl_xor(v[j], 2, 64);
+    }
+    if (part == 0) {
+      float* d = jb.gdst + (int64_t)r * jb.g_ld + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c + j < jb.ncols) d[j] = v[j];
+    }
   }
 }
 

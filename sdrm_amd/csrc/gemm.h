@@ -38,11 +38,11 @@ enum : int {
   EPI_PLAIN = 5          // C = acc (debug)
 };
 
-constexpr int BK = 16, NTHREADS = 256;
+constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4>
+template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4, int BK_ = 16>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
   static constexpr int MINW = MINW_;   // waves per SIMD the register allocator must leave room for
   static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;   // MFMA tiles per wave
   static constexpr int LDA = BM_ + 4, LDB = BN_ + 4;               // LDS row strides (floats)
@@ -55,8 +55,8 @@ struct GemmArgs {
   const float* A; int lda; int limA;   // limA: valid extent of A's output-side index (multiple of 32)
   const float* B; int ldb; int limB;
   float* C; int ldc;
-  int K;            // full reduction length (multiple of BK)
-  int kchunk;       // reduction range handled by one blockIdx.z (multiple of BK)
+  int K;            // full reduction length (multiple of 32)
+  int kchunk;       // reduction range handled by one blockIdx.z (multiple of 32)
   int tiles_n;      // number of tiles along N (grid.x = tiles_m * tiles_n, XCD-swizzled)
   int nblocks;      // tiles_m * tiles_n
   const float* bias;
@@ -72,19 +72,28 @@ struct GemmArgs {
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
 
+// tanh through the hardware exp2/rcp: 1 - 2/(e^{2x}+1).  Absolute error ~1e-7 (the eps-net output is
+// compared at 1e-4 of max|y| ~ 0.3); libm's tanhf costs ~30 instructions per element, which on a
+// 64-element-per-thread epilogue is microseconds per work-group.
+__device__ __forceinline__ float tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);   // e^{2x} = 2^{2x*log2(e)}
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 // Global -> registers for one operand tile (ROWS x BK elements, ROWS = BM or BN).  No bounds checks:
 // every operand buffer is allocated with its tiled extent (rows rounded up to the tile, plus a slack
 // tail), rows/cols beyond the matrix feed only output rows/cols the epilogue discards, and weight pad
 // rows are zero.  Branch-free loads are what lets the compiler keep them in flight behind counted waits.
-template <int LOAD, int ROWS>
+template <int LOAD, int ROWS, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int i0, int k0,
                                           float4 (&r)[ROWS * BK / 4 / NTHREADS], int tid) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
+  constexpr int KQ = BK / 4;   // float4 per row of a k-contiguous operand
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
     if (LOAD == LD_KCONTIG) {
-      const int i = f >> 2, kq = f & 3;
+      const int i = f / KQ, kq = f % KQ;
       r[s] = *reinterpret_cast<const float4*>(src + (size_t)(i0 + i) * ld + k0 + 4 * kq);
     } else {
       constexpr int VPR = ROWS / 4;  // float4 per k-row
@@ -96,10 +105,11 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
 
 // Registers -> LDS (k-major, row stride LD).  The operand transform (PReLU of stored pre-activations)
 // is applied here, not at load time, so the global loads stay in flight across two K-steps.
-template <int LOAD, int XF, int ROWS, int LD>
+template <int LOAD, int XF, int ROWS, int LD, int BK>
 __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4 (&r)[ROWS * BK / 4 / NTHREADS],
                                            float slope, int tid) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
+  constexpr int KQ = BK / 4;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
     const int f = tid + s * NTHREADS;
@@ -108,7 +118,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4
       v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope); v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
     }
     if (LOAD == LD_KCONTIG) {
-      const int i = f >> 2, kq = f & 3;
+      const int i = f / KQ, kq = f % KQ;
       float* d = dst + (4 * kq) * LD + i;
       d[0] = v.x; d[LD] = v.y; d[2 * LD] = v.z; d[3 * LD] = v.w;
     } else {
@@ -129,7 +139,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
 __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArgs p) {
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, TM = Cfg::TM, TN = Cfg::TN, LDA = Cfg::LDA, LDB = Cfg::LDB;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN;
+  // LDS row strides: +2 floats for transposing (k-contiguous) stores, which makes the 4*kq*LD + i bank pattern
+  // of a half-wave at most 2-way (free) for BK = 16 and 32; +4 keeps ds_write_b128 rows 16-byte aligned.
+  constexpr int LDA = BM + (LOADA == LD_KCONTIG ? 2 : 4), LDB = BN + (LOADB == LD_KCONTIG ? 2 : 4);
   constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
   static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
@@ -168,13 +181,13 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 
   auto ld = [&](float4 (&xa)[NVA], float4 (&xb)[NVB], int i) {
     const int k0 = kb + min(i, nt - 1) * BK;   // past the end: re-read the last K-step (never consumed)
-    load_tile<LOADA, BM>(p.A, p.lda, m0, k0, xa, tid);
-    load_tile<LOADB, BN>(p.B, p.ldb, n0, k0, xb, tid);
+    load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid);
+    load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid);
   };
   auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
     float* An = smem + stage * Cfg::STAGE;
-    store_tile<LOADA, XFA, BM, LDA>(An, xa, slopeA, tid);
-    store_tile<LOADB, XFB, BN, LDB>(An + BK * LDA, xb, slopeB, tid);
+    store_tile<LOADA, XFA, BM, LDA, BK>(An, xa, slopeA, tid);
+    store_tile<LOADB, XFB, BN, LDB, BK>(An + BK * LDA, xb, slopeB, tid);
   };
   auto compute = [&](int stage) {
     const float* As = smem + stage * Cfg::STAGE;
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanhf(acc[a][b][r] + bias);
+          if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanh_fast(acc[a][b][r] + bias);
         }
       } else if (EPI == EPI_DPRELU) {
         const float* __restrict__ auxp = p.aux;

@@ -19,7 +19,7 @@ namespace {
 
 constexpr int BM = 128, BN = 128;   // row padding granule / reference tile for split sizing
 constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
-constexpr int TARGET_BLOCKS = 512; // work-groups a wgrad launch aims for (2 per CU)
+constexpr int TARGET_BLOCKS = 1024; // work-groups a wgrad launch aims for (4 per CU)
 constexpr int LOSS_BLOCKS = 256;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -108,30 +108,25 @@ const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
 struct Prof { sdrm_engine* e; int cls; double flops; };
 
-typedef TileCfg<128, 128, 2, 2> Cfg128x128;
-typedef TileCfg<64, 128, 2, 2> Cfg64x128;
-constexpr int N_TILE_CFGS = 2;
-const int kCfgBM[N_TILE_CFGS] = {128, 64};
-const int kCfgBN[N_TILE_CFGS] = {128, 128};
-int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override
+// Tile shapes.  Measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt): the smallest
+// tile with the shortest K-step wins on every shape of this workload (103 TF at 24576x352x352 vs 78 TF
+// for 128x128x16): K is only ~350 deep, so a block is mostly prologue/epilogue and per-K-step barrier
+// latency, and what hides that is many co-resident blocks (17 KB of LDS -> 9 per CU), not a big tile.
+typedef TileCfg<64, 64, 2, 2, 4, 16> Cfg0;     //  64x 64x16  (default)
+typedef TileCfg<64, 64, 2, 2, 4, 32> Cfg1;     //  64x 64x32
+typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
+typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
+constexpr int N_TILE_CFGS = 4;
+const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128};
+const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128};
+int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
 
-// Pick the tile shape whose busiest CU finishes first: blocks are dealt round-robin over 256 CUs, the
-// ones resident together on a CU share its matrix pipes, so time ~ ceil(blocks/256) * BM*BN / eff.
-int pick_cfg(int M, int N) {
-  if (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) return g_force_cfg;
-  const double eff[N_TILE_CFGS] = {1.0, 0.9};
-  int best = 0;
-  double best_cost = 1e300;
-  for (int c = 0; c < N_TILE_CFGS; ++c) {
-    const long blocks = (long)((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
-    const double cost = (double)((blocks + 255) / 256) * kCfgBM[c] * kCfgBN[c] / eff[c];
-    if (cost < best_cost) { best_cost = cost; best = c; }
-  }
-  return best;
+int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
+  return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
 }
 
-int gemm_blocks(int M, int N) {
-  const int c = pick_cfg(M, N);
+int gemm_blocks(int M, int N, int K) {
+  const int c = pick_cfg(M, N, K);
   return ((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
 }
 
@@ -169,10 +164,12 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
 template <int LA, int LB, int XA, int XB, int EPI>
 hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0},
                        int cfg = -1) {
-  if (cfg < 0) cfg = pick_cfg(M, N);
+  if (cfg < 0) cfg = pick_cfg(M, N, a.kchunk);
   switch (cfg) {
-    case 1: return launch_gemm_cfg<Cfg64x128, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
-    default: return launch_gemm_cfg<Cfg128x128, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    case 1: return launch_gemm_cfg<Cfg1, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    case 2: return launch_gemm_cfg<Cfg2, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    case 3: return launch_gemm_cfg<Cfg3, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    default: return launch_gemm_cfg<Cfg0, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
   }
 }
 
@@ -188,14 +185,15 @@ hipError_t gemm_forward(GemmArgs a, const float* A, int lda, const float* Wc, in
 
 // dgrad: C[M,Kin] = (dC[M,Nout] * Wc[Nout,Kin]) * prelu'(aux)
 hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* Wc, int ldw, int M, int Nout, int Kin,
-                      float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st, double flops) {
+                      float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st, double flops,
+                      int cfg) {
   GemmArgs a{};
   a.A = dC; a.lda = lddc; a.limA = M;
   a.B = Wc; a.ldb = ldw; a.limB = Kin;
   a.C = out; a.ldc = e->WP;
   a.K = Nout; a.kchunk = Nout;
   a.aux = aux; a.ldaux = e->WP; a.slopeE = slopeE; a.slope_partial = partial;
-  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st, Prof{e, PC_DGRAD, flops});
+  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st, Prof{e, PC_DGRAD, flops}, cfg);
 }
 
 // wgrad: slab[s][Nout,Kin] = dC[rows s][.,Nout]^T * xf(Act)[rows s][., Kin] ; dbias[s][Nout] = column sums of dC
@@ -214,7 +212,9 @@ hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int
 }
 
 void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
-  const int tiles = ((Nout + BM - 1) / BM) * ((Kin + BN - 1) / BN);
+  const int c = pick_cfg(Nout, Kin, 4096);
+  const int tiles = ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
+  const int BK = 32;
   int want = TARGET_BLOCKS / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
   if (max_by_rows < 1) max_by_rows = 1;
@@ -356,8 +356,8 @@ int sdrm_debug_set_tile(int cfg) {
 }
 
 const char* sdrm_build_info(void) {
-  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tiles 128x128x16 / 64x128x16 chosen per launch, 4 waves, LDS "
-         "double-buffered; split-K slabs for wgrad";
+  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (alternates 64x64x32, 64x128x16, 128x128x16), 4 waves, "
+         "LDS double-buffered, distance-2 register prefetch; split-K slabs for wgrad";
 }
 
 const char* sdrm_last_error(const sdrm_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -569,7 +569,9 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   pick_splits(MP, e->WP, e->K0, S0, kc0);
   pick_splits(MP, e->WP, e->WP, SH, kcH);
   pick_splits(MP, e->LP, e->WP, SO, kcO);
-  const int dgrad_blocks = gemm_blocks(MP, e->WP);  // every dgrad writes [MP,WP]: same tile shape, same count
+  // every dgrad writes [MP,WP]: one tile shape for all of them, so the slope partial counts agree
+  const int cfg_d = pick_cfg(MP, e->WP, e->WP);
+  const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   // output layer
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W,
                fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
@@ -578,14 +580,14 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   float* dcur = e->dA;
   float* dnext = e->dB;
   HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->Woc, e->WP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
-                        e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO));
+                        e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO, cfg_d));
   // shared hidden layer, applications H..1
   for (int k = H; k >= 1; --k) {
     HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dcur, e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
                                      kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
                                      e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
     HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
-                          slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH));
+                          slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
     float* tmp = dcur; dcur = dnext; dnext = tmp;
   }
   // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0

@@ -36,11 +36,11 @@ def run(variant, M, N, K, cfg, reps=50):
 if __name__ == "__main__":
     ncfg = int(os.environ.get("NCFG", "2"))
     for variant, M, N, K, label in SHAPES:
-        row = [f"{label:34s} v{variant} {M:6d}x{N:4d}x{K:6d}"]
-        for cfg in range(ncfg):
+        row = [f"{label[:22]:22s} v{variant} {M:6d}x{N:4d}x{K:6d}"]
+        for cfg in [int(c) for c in os.environ.get("CFGS", ",".join(str(i) for i in range(ncfg))).split(",")]:
             try:
                 us, tf = run(variant, M, N, K, cfg)
-                row.append(f"cfg{cfg}: {us:8.1f}us {tf:6.1f}TF")
+                row.append(f"c{cfg}:{us:7.1f}us{tf:6.1f}TF")
             except AssertionError as exc:
                 row.append(f"cfg{cfg}: n/a({exc})")
         print("  ".join(row), flush=True)
