@@ -59,6 +59,7 @@ struct GemmArgs {
   int kchunk;       // reduction range handled by one blockIdx.z (multiple of 32)
   int tiles_n;      // number of tiles along N (grid.x = tiles_m * tiles_n, XCD-swizzled)
   int nblocks;      // tiles_m * tiles_n
+  int nsplits;      // K-slices (EPI_SLAB only; 1 otherwise)
   const float* bias;
   const float* slopeA;  // PReLU slope applied to A elements on load (XF_PRELU)
   const float* slopeB;
@@ -66,6 +67,7 @@ struct GemmArgs {
   const float* aux; int ldaux; const float* slopeE; float* slope_partial;
   // EPI_SLAB
   size_t slab_stride; float* dbias; int dbias_stride;
+  unsigned long long* stamps;   // diagnostic builds only (-DSDRM_STAMPS): 4 s_memtime stamps per block
   // EPI_BIAS_TANH: output may be an unpadded caller buffer
   int rows_valid, cols_valid;
 };
@@ -152,10 +154,22 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
-  const int logical = xcd_remap(blockIdx.x, p.nblocks);
+  int logical, split;
+  if (EPI == EPI_SLAB) {
+    // split-K launch: all tiles of one K-slice go to ONE XCD (blocks are dealt round-robin over the 8
+    // XCDs), so the slice's two operand strips (a few MB) are fetched from HBM once and re-read from that
+    // XCD's L2 by the other tiles.  Spread over XCDs they were fetched 4.6x (measured: FETCH_SIZE).
+    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = (slot / p.nblocks) * 8 + x;
+    logical = slot % p.nblocks;
+    if (split >= p.nsplits) return;
+  } else {
+    logical = xcd_remap(blockIdx.x, p.nblocks);
+    split = 0;
+  }
   const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int kb = blockIdx.z * p.kchunk;
+  const int kb = split * p.kchunk;
   const int ke = min(kb + p.kchunk, p.K);
 
   const float slopeA = (XFA == XF_PRELU) ? *p.slopeA : 0.f;
@@ -189,9 +203,14 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     store_tile<LOADA, XFA, BM, LDA, BK>(An, xa, slopeA, tid);
     store_tile<LOADB, XFB, BN, LDB, BK>(An + BK * LDA, xb, slopeB, tid);
   };
+  // A wave whose whole 32-granular tile range lies outside the matrix (the half-empty last tile row /
+  // column: 352 = 5.5 x 64) issues no LDS reads and no MFMAs; it still loads, stores and meets the
+  // barriers.  Its SIMD's matrix pipe goes to the other work-groups resident on the CU.
+  const bool wave_active = (m0 + wm * (BM / Cfg::WM) < p.limA) && (n0 + wn * (BN / Cfg::WN) < p.limB);
   auto compute = [&](int stage) {
     const float* As = smem + stage * Cfg::STAGE;
     const float* Bs = As + BK * LDA;
+    if (wave_active) {
     // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
     // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
     float af[2][TM], bf[2][TN];
@@ -216,18 +235,26 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     if (do_dbias) {
 #pragma unroll
       for (int k = 0; k < BK; ++k) dbsum += As[k * LDA + tid];
     }
   };
 
+#ifdef SDRM_STAMPS
+  unsigned long long t_in = 0, t_pro = 0, t_loop = 0;
+  if (EPI == EPI_PLAIN) t_in = __builtin_amdgcn_s_memtime();
+#endif
   if (nt > 0) {
     ld(ra0, rb0, 0);
     st(ra0, rb0, 0);
     ld(ra0, rb0, 1);
     ld(ra1, rb1, 2);
     __syncthreads();
+#ifdef SDRM_STAMPS
+    if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
+#endif
     int i = 0;
     for (; i + 1 < nt; i += 2) {
       st(ra0, rb0, 1);          // set 0 holds K-step i+1
@@ -241,6 +268,9 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     }
     if (i < nt) compute(0);     // odd count: the last K-step already sits in stage 0
   }
+#ifdef SDRM_STAMPS
+  if (EPI == EPI_PLAIN) t_loop = __builtin_amdgcn_s_memtime();
+#endif
 
   // ------------------------------------------------------------------ epilogue
   // accumulator register r of tile (a,b): row = m0 + wm*(BM/WM) + a*32 + (r&3) + 8*(r>>2) + 4*lhi,
@@ -285,7 +315,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
           slope_sum += pos ? 0.f : v * pre[r];
         }
       } else if (EPI == EPI_SLAB) {
-        float* __restrict__ Sp = p.C + (size_t)blockIdx.z * p.slab_stride;
+        float* __restrict__ Sp = p.C + (size_t)split * p.slab_stride;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -295,6 +325,13 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     }
   }
 
+#ifdef SDRM_STAMPS
+  if (EPI == EPI_PLAIN && p.stamps && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* o = p.stamps + 4 * (size_t)blockIdx.x;
+    o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   if (EPI == EPI_DPRELU) {
     // block-wide sum of the slope-gradient partial -> one float per block (deterministic order)
 #pragma unroll
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     if (tid == 0) p.slope_partial[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
   }
   if (EPI == EPI_SLAB) {
-    if (do_dbias && (m0 + tid) < p.limA) p.dbias[(size_t)blockIdx.z * p.dbias_stride + m0 + tid] = dbsum;
+    if (do_dbias && (m0 + tid) < p.limA) p.dbias[(size_t)split * p.dbias_stride + m0 + tid] = dbsum;
   }
 }
 

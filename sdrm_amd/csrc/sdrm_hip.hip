@@ -144,7 +144,8 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
   const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
   a.tiles_n = tiles_n;
   a.nblocks = tiles_m * tiles_n;
-  dim3 grid(a.nblocks, 1, splits);
+  a.nsplits = splits;
+  dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * ((splits + 7) / 8) * 8) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
   const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
   size_t slot = 0;
@@ -221,6 +222,8 @@ void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
   S = want < 1 ? 1 : want;
   if (S > S_MAX) S = S_MAX;
   if (S > max_by_rows) S = max_by_rows;
+  if (S >= 8) S = (S + 4) / 8 * 8;   // K-slices are dealt to the 8 XCDs: keep them balanced
+  if (S > S_MAX) S = S_MAX;
   kchunk = round_up((Mrows + S - 1) / S, BK);
   S = (Mrows + kchunk - 1) / kchunk;
 }
@@ -885,6 +888,33 @@ int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M
 
 /* Timing variant of the hook for tools/gemm_tune.py: same kernel, `reps` launches on pre-padded scratch,
  * returns the mean microseconds per launch measured with HIP events on `stream`. */
+#ifdef SDRM_STAMPS
+extern "C" int sdrm_debug_gemm_stamps(int variant, int M, int N, int K, unsigned long long* host_out, int max_blocks) {
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
+  const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
+  const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;
+  float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  unsigned long long* dS = nullptr;
+  if (dalloc(&dA, (size_t)ar * ac) != hipSuccess || dalloc(&dB, (size_t)br * bc) != hipSuccess ||
+      dalloc(&dC, (size_t)Mp * Np) != hipSuccess || dalloc(&dS, (size_t)4 * max_blocks) != hipSuccess)
+    return SDRM_ERR_NOMEM;
+  GemmArgs a{};
+  a.C = dC; a.ldc = Np; a.K = K; a.kchunk = K; a.stamps = dS;
+  a.A = dA; a.lda = ac; a.limA = M; a.B = dB; a.ldb = bc; a.limB = N;
+  hipError_t rc = hipSuccess;
+  for (int i = 0; i < 3 && rc == hipSuccess; ++i) {
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
+  }
+  if (rc == hipSuccess) rc = hipDeviceSynchronize();
+  const int nb = a.nblocks < max_blocks ? a.nblocks : max_blocks;
+  if (rc == hipSuccess) rc = hipMemcpy(host_out, dS, (size_t)nb * 32, hipMemcpyDeviceToHost);
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dS);
+  return rc == hipSuccess ? nb : SDRM_ERR_HIP;
+}
+#endif
+
 int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_out, void* stream) {
   if (!us_out || reps < 1 || M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2) return SDRM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
