@@ -207,34 +207,44 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   // column: 352 = 5.5 x 64) issues no LDS reads and no MFMAs; it still loads, stores and meets the
   // barriers.  Its SIMD's matrix pipe goes to the other work-groups resident on the CU.
   const bool wave_active = (m0 + wm * (BM / Cfg::WM) < p.limA) && (n0 + wn * (BN / Cfg::WN) < p.limB);
+  // compute() is split in two so that a K-step can issue its first fragment reads right after the
+  // barrier, ahead of the LDS stores of the next step's operands (they queue in order on the LDS
+  // pipe): the first MFMA then waits ~one LDS latency instead of stores + latency.
+  float af[2][TM], bf[2][TN];
+  auto first_frags = [&](int stage) {
+    const float* As = smem + stage * Cfg::STAGE;
+    const float* Bs = As + BK * LDA;
+    if (wave_active) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + 32 * a];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + 32 * b];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto compute = [&](int stage) {
     const float* As = smem + stage * Cfg::STAGE;
     const float* Bs = As + BK * LDA;
     if (wave_active) {
-    // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
-    // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
-    float af[2][TM], bf[2][TN];
+      // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
+      // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
 #pragma unroll
-    for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + 32 * a];
+      for (int s = 0; s < BK / 2; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < BK / 2) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + 32 * b];
+          for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + 2 * (s + 1) * LDA + 32 * a];
 #pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      const int cur = s & 1, nxt = cur ^ 1;
-      if (s + 1 < BK / 2) {
+          for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + 2 * (s + 1) * LDB + 32 * b];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + 2 * (s + 1) * LDA + 32 * a];
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + 2 * (s + 1) * LDB + 32 * b];
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     }
     if (do_dbias) {
 #pragma unroll
@@ -242,10 +252,6 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     }
   };
 
-#ifdef SDRM_STAMPS
-  unsigned long long t_in = 0, t_pro = 0, t_loop = 0;
-  if (EPI == EPI_PLAIN) t_in = __builtin_amdgcn_s_memtime();
-#endif
   if (nt > 0) {
     ld(ra0, rb0, 0);
     st(ra0, rb0, 0);
@@ -257,16 +263,18 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 #endif
     int i = 0;
     for (; i + 1 < nt; i += 2) {
+      first_frags(0);
       st(ra0, rb0, 1);          // set 0 holds K-step i+1
       ld(ra0, rb0, i + 3);
       compute(0);
       __syncthreads();
+      first_frags(1);
       st(ra1, rb1, 0);          // set 1 holds K-step i+2
       ld(ra1, rb1, i + 4);
       compute(1);
       __syncthreads();
     }
-    if (i < nt) compute(0);     // odd count: the last K-step already sits in stage 0
+    if (i < nt) { first_frags(0); compute(0); }   // odd count: the last K-step already sits in stage 0
   }
 #ifdef SDRM_STAMPS
   if (EPI == EPI_PLAIN) t_loop = __builtin_amdgcn_s_memtime();

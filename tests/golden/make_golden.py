@@ -508,13 +508,70 @@ def fixture_host(ref):
     np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
 
 
+def fixture_ml100k(ref):
+    """The reference's ML-100k split (data/ml-100k/*.pkl, binary CSR) in a compact form: data, not code."""
+    import pickle
+    out = {}
+    for tag in ("train_test", "valid"):
+        m = pickle.load(open(os.path.join(REFERENCE, "data", "ml-100k", f"ml-100k_{tag}.pkl"), "rb")).tocsr()
+        m.sort_indices()
+        assert set(np.unique(m.data)) <= {0, 1} and m.shape[1] < 65536     # explicit zeros are kept: the split helper
+        out[tag + "_data"] = m.data.astype(np.uint8)                        # counts stored entries, not values
+        out[tag + "_indptr"] = m.indptr.astype(np.int32)
+        out[tag + "_indices"] = m.indices.astype(np.uint16)
+        out[tag + "_shape"] = np.asarray(m.shape, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "ml100k.npz"), **out)
+
+
+def fixture_e2e(ref):
+    """End-to-end Recall@k / NDCG@k band of the reference on ML-100k / SVD (README hyper-parameters,
+    main.py:143-200 restated as a driver), seeds 0..4, CPU.  ~2 minutes per seed."""
+    import dataloaders as refdl
+    import svd_benchmark as refsvd
+    import pandas as pd
+    ref.VAE.get_l2_reg = lambda self: 0.0 * next(self.parameters()).sum()   # the original calls .cuda() (Q12)
+    hp = dict(epochs=265, batch=550, lr=2.1e-5, T=83, nd=1.0, H=2, vae_batch=780, vae_hidden=930, latent=830, vae_lr=6e-4)
+    train, train_partial, valid = refdl.load_data("ml-100k", os.path.join(REFERENCE, "data"))
+    n_items, n_users = train.shape[1], train.shape[0]
+    sparsity = 1 - train.nnz / (train.shape[0] * train.shape[1])
+    res = {"seeds": [], "M_recall": [], "M_ndcg": [], "F_recall": [], "F_ndcg": [], "V_recall": [], "V_ndcg": []}
+    seeds = [int(x) for x in os.environ.get("E2E_SEEDS", "0,1,2,3,4").split(",")]
+    for seed in seeds:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        ds = refdl.SparseDataset(train_partial, train_partial)
+        sampler = torch.utils.data.sampler.BatchSampler(
+            torch.utils.data.sampler.RandomSampler(ds, generator=torch.Generator(device="cpu")), batch_size=hp["batch"], drop_last=False)
+        dl = torch.utils.data.DataLoader(ds, batch_size=1, collate_fn=refdl.sparse_batch_collate,
+                                         generator=torch.Generator(device="cpu"), sampler=sampler, shuffle=False)
+        net, vae = ref.train_SDRM(dl=dl, N_ITEMS=n_items, VAE_LATENT=hp["latent"], VAE_HIDDEN=hp["vae_hidden"], VAE_LR=hp["vae_lr"],
+                                  VAE_BATCH_SIZE=hp["vae_batch"], DIFF_LATENT=hp["latent"], DIFF_TRAINING_EPOCHS=hp["epochs"],
+                                  DIFF_LR=hp["lr"], N_HIDDEN_MLP_LAYERS=hp["H"], TIMESTEPS=hp["T"], noise_divider=hp["nd"],
+                                  VAE_DIR_PATH=f"/tmp/ref_vae_{seed}", TRAIN_PARTIAL_VALID_DATA=train_partial, VALID_DATA=valid,
+                                  OPTIMIZATION_OBJECTIVE="Recall@10", verbose=False)
+        M = ref.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], timesteps="random", n_timesteps=hp["T"]).detach().cpu().numpy()
+        F_ = ref.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], n_timesteps=hp["T"]).detach().cpu().numpy()
+        V = vae.sample(n_users)
+        for tag, raw in (("M", M), ("F", F_), ("V", V)):
+            binar = pd.DataFrame((raw >= np.quantile(raw.flatten(), sparsity)).astype(int))
+            rec, ndcg = refsvd.compute_mf_results(train, valid, synthetic_data=binar, nnmf=False, only_synthetic=True)
+            res[tag + "_recall"].append(rec); res[tag + "_ndcg"].append(ndcg)
+        res["seeds"].append(seed)
+        print("seed", seed, "M", res["M_recall"][-1][3], "F", res["F_recall"][-1][3], "V", res["V_recall"][-1][3], flush=True)
+    out = {k: np.asarray(v) for k, v in res.items()}
+    out["k"] = np.asarray([1, 3, 5, 10, 20, 50])
+    out["hyper"] = np.asarray([hp["epochs"], hp["batch"], hp["lr"], hp["T"], hp["nd"], hp["H"], hp["vae_batch"], hp["vae_hidden"],
+                               hp["latent"], hp["vae_lr"]])
+    np.savez_compressed(os.path.join(HERE, "e2e_ml100k_svd.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
     which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host"]
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
              "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
-             "fullsize": fixture_fullsize, "host": fixture_host}
+             "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e}
     for w in which:
         table[w](ref)
         print("wrote", w)
