@@ -140,6 +140,24 @@ def cpu_baseline(wl, seconds_budget=25.0):
                       f"same 15:78 mix, oracle/sdrm_oracle.py on torch CPU ops, {cores} threads, {dt:.1f} s"}
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json,
+    made by tools/pmc_summary.py from two separate `rocprofv3 --pmc` runs of this same command; gfx950
+    FETCH_SIZE correction applied there).  None if no such file travels with the repo."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")))
+    m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
+    if not files or not m:
+        return None, None
+    needle = ", " + ", ".join(m.groups()) + ">("
+    data = json.load(open(files[-1]))
+    for name, v in data.get("kernels", {}).items():
+        if needle in name:
+            return v["hbm_bytes_per_launch_mean"], os.path.basename(files[-1])
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,8 +243,10 @@ def main():
         if dom:
             name, (ms, launches, flops) = dom
             achieved = flops / (ms * 1e-3) / 1e12
+            traffic, src = pmc_traffic(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": src,
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "launches": launches,
                     "algorithmic_flops_per_launch": flops / launches,
                     "all_kernels": {k: {"ms": round(v[0], 3), "launches": v[1],
