@@ -491,29 +491,26 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
 
 // ---------------------------------------------------------------------------------------------
 // Sampling helpers.
+// Sampler state: slot s of X/U holds original row rowid[s] (identity when rowid == null).  For the
+// multi-resolution branch the host orders slots by DESCENDING start step Tj, so the rows active at step i
+// (Tj >= i) are always the prefix [0, n_act(i)) and every step's GEMMs run on exactly the active rows —
+// the same row-steps as the reference's per-user batch-1 loops (train_SDRM.py:40-48), batched.
+// U[s] is pre-loaded with the dropout of the row's OWN first step (keep mask of step Tj[s]).
 struct SampleInitArgs {
-  const float* xT; const uint8_t* keep; const int64_t* Tj_in; int64_t* Tj_dev; int64_t* Tj_out;
-  float* X; float* U; int n, L, LP, K0, MP, T, i_start;
-  int mode, multires; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
+  const float* xT; const uint8_t* keep; const int64_t* Tj; const int* rowid;
+  float* X; float* U; int n, L, LP, K0, MP, T;
+  int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
 };
 
 __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
-  const int r = blockIdx.y;
+  const int s = blockIdx.y;
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int c = 2 * q;
-  if (c >= a.LP || r >= a.MP) return;
+  if (c >= a.LP || s >= a.MP) return;
   float x[2] = {0.f, 0.f}, u[2] = {0.f, 0.f};
-  if (r < a.n) {
-    if (q == 0 && a.Tj_dev) {
-      int64_t tj;
-      if (a.mode == 0) tj = a.Tj_in[r];
-      else {
-        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), 0u, PURPOSE_SAMPLE_TJ, a.call_id, a.seed_lo, a.seed_hi);
-        tj = 1 + (int64_t)bounded(w.x, (uint32_t)max(a.T - 1, 1));  // np.random.randint(1, T), :42
-      }
-      a.Tj_dev[r] = tj;
-      if (a.Tj_out) a.Tj_out[r] = tj;
-    }
+  if (s < a.n) {
+    const int r = a.rowid ? a.rowid[s] : s;
+    const int first = a.Tj ? (int)a.Tj[s] : a.T;   // the step this row starts at
     if (c < a.L) {
       uint32_t bits = 0;
       float nrm[2] = {0.f, 0.f};
@@ -521,8 +518,8 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
         const uint32_t grow = (uint32_t)(a.row0 + r);
         const U4 w = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_XT, a.call_id, a.seed_lo, a.seed_hi);
         box_muller(w.x, w.y, nrm[0], nrm[1]);
-        // the keep bits of step i ride on the Philox call that draws z_{i+1} (see EPI_TANH_REVERSE)
-        const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)(a.i_start + 1) << 8), a.call_id,
+        // the keep bits of step i ride on the Philox call that draws z_{i+1} (see k_reverse_update)
+        const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)(first + 1) << 8), a.call_id,
                                     a.seed_lo, a.seed_hi);
         bits = w2.z;
       }
@@ -532,14 +529,14 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
         if (cc < a.L) {
           const size_t idx = (size_t)r * a.L + cc;
           x[j] = (a.mode == 0) ? a.xT[idx] : nrm[j];
-          const bool k = (a.mode == 0) ? (a.keep[idx] != 0) : (((bits >> (8 * j)) & 1u) != 0);
+          const bool k = (a.mode == 0) ? (a.keep[(size_t)first * a.n * a.L + idx] != 0) : (((bits >> (8 * j)) & 1u) != 0);
           u[j] = k ? 2.f * x[j] : 0.f;
         }
       }
     }
   }
-  *reinterpret_cast<float2*>(a.X + (size_t)r * a.LP + c) = make_float2(x[0], x[1]);
-  *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = make_float2(u[0], u[1]);
+  *reinterpret_cast<float2*>(a.X + (size_t)s * a.LP + c) = make_float2(x[0], x[1]);
+  *reinterpret_cast<float2*>(a.U + (size_t)s * a.K0 + c) = make_float2(u[0], u[1]);
 }
 
 // One DDPM reverse update on the sampler's padded state (denoise_add_noise, train_SDRM.py:20-25) fused
@@ -549,20 +546,21 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
 // One thread per column pair: in PHILOX mode one Philox call yields the pair's two normals z_i and the
 // pair's keep bits for step i-1.
 struct ReverseArgs {
-  float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj;
+  float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj; const int* rowid;
   int n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
   int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
 };
 
 __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
-  const int r = blockIdx.y;
+  const int s = blockIdx.y;                      // slot; rows [0, n) of this launch are the active prefix
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int c = 2 * q;
-  if (c >= a.L || r >= a.n) return;
-  const size_t xi = (size_t)r * a.LP + c;
+  if (c >= a.L || s >= a.n) return;
+  const int r = a.rowid ? a.rowid[s] : s;       // original row: indexes explicit randoms and keys Philox
+  const size_t xi = (size_t)s * a.LP + c;
   const float2 xo = *reinterpret_cast<const float2*>(a.X + xi);
   const float2 e = *reinterpret_cast<const float2*>(a.Y + xi);
-  const bool active = (a.Tj == nullptr) || (a.Tj[r] >= (int64_t)a.step_i);
+  const bool active = (a.Tj == nullptr) || (a.Tj[s] >= (int64_t)a.step_i);
   float z[2] = {0.f, 0.f};
   bool kp[2] = {false, false};
   if (a.step_i > 1) {
@@ -587,14 +585,15 @@ __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
   xn[1] = (c + 1 < a.L) ? (active ? (xo.y - e.y * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[1] : xo.y) : 0.f;
   *reinterpret_cast<float2*>(a.X + xi) = make_float2(xn[0], xn[1]);
   if (a.step_i > 1)
-    *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = make_float2(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f);
+    *reinterpret_cast<float2*>(a.U + (size_t)s * a.K0 + c) = make_float2(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f);
 }
 
-__global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L) {
+__global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L, const int* rowid) {
   const size_t total = (size_t)n * L;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / L), c = (int)(i - (size_t)r * L);
-    dst[i] = src[(size_t)r * ld + c];
+    const int s = (int)(i / L), c = (int)(i - (size_t)s * L);
+    const int r = rowid ? rowid[s] : s;
+    dst[(size_t)r * L + c] = src[(size_t)s * ld + c];
   }
 }
 

@@ -2,6 +2,7 @@
 // Host logic only: buffer ownership, launch orchestration of the train step / sampler, error codes.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,9 @@ struct sdrm_engine {
   float *dC0 = nullptr, *dE = nullptr;
   int *tdev = nullptr;
   int64_t *Tj_dev = nullptr;
+  int *rowid_dev = nullptr;
+  std::vector<int> smp_nact, smp_perm;
+  std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
   std::vector<float> h_beta, h_alpha, h_alphabar;
   int64_t adam_t = 0;
   // state of the last train_forward
@@ -418,7 +422,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
   HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
   HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
-  HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows));
+  HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
   int rc = upload_schedule(e, 1e-4f, 0.02f);
   if (rc) return rc;
   rc = upload_temb(e);
@@ -432,7 +436,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->dB, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -722,14 +726,45 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   e->fwd_done = false;
   int rc = emb_tables(e, true, st);
   if (rc) return rc;
-  // PHILOX multi-resolution draws Tj in [1, T-1] (np.random.randint(1, T), :42), so step T is never active
-  const int i_start = (multires && mode == SDRM_RNG_PHILOX && T > 1) ? T - 1 : T;
-  const size_t nL = (size_t)n * L;
+  int i_start = T;
+  e->smp_nact.assign(T + 2, n);                       // n_act[i] = rows with Tj >= i (all rows when full resolution)
+  if (multires) {
+    // Start steps on the host: drawn with the same Philox call the device would make (PHILOX), or copied
+    // back (EXPLICIT; one sync per sampling call).  Slots are then ordered by descending Tj.
+    std::vector<int64_t> tj(n);
+    if (mode == SDRM_RNG_PHILOX) {
+      for (int r = 0; r < n; ++r) {
+        const U4 w = philox4x32_10((uint32_t)(row0 + r), 0u, PURPOSE_SAMPLE_TJ, (uint32_t)call_id, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+        tj[r] = 1 + (int64_t)bounded(w.x, (uint32_t)(T - 1 > 1 ? T - 1 : 1));   // np.random.randint(1, T), :42
+      }
+    } else {
+      HIP_TRY(e, hipMemcpyAsync(tj.data(), Tj, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(e, hipStreamSynchronize(st));
+      for (int r = 0; r < n; ++r) tj[r] = tj[r] < 0 ? 0 : (tj[r] > T ? T : tj[r]);
+    }
+    std::vector<int> perm(n);
+    for (int r = 0; r < n; ++r) perm[r] = r;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return tj[a] > tj[b]; });
+    e->smp_tj_sorted.resize(n);
+    for (int s = 0; s < n; ++s) e->smp_tj_sorted[s] = tj[perm[s]];
+    e->smp_perm = perm;
+    std::vector<int> hist(T + 2, 0);
+    for (int r = 0; r < n; ++r) hist[(int)tj[r]]++;
+    int acc = 0;
+    for (int i = T; i >= 0; --i) { acc += hist[i]; e->smp_nact[i] = acc; }
+    i_start = (int)e->smp_tj_sorted[0];
+    HIP_TRY(e, hipMemcpyAsync(e->rowid_dev, e->smp_perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(e, hipMemcpyAsync(e->Tj_dev, e->smp_tj_sorted.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    if (Tj_out) {
+      e->smp_tj_orig = tj;
+      HIP_TRY(e, hipMemcpyAsync(Tj_out, e->smp_tj_orig.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+  }
   SampleInitArgs ia{};
-  ia.xT = xT; ia.keep = keep ? keep + (size_t)i_start * nL : nullptr; ia.Tj_in = Tj;
-  ia.Tj_dev = multires ? e->Tj_dev : nullptr; ia.Tj_out = multires ? Tj_out : nullptr;
-  ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T; ia.i_start = i_start;
-  ia.mode = mode; ia.multires = multires; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
+  ia.xT = xT; ia.keep = keep; ia.Tj = multires ? e->Tj_dev : nullptr; ia.rowid = multires ? e->rowid_dev : nullptr;
+  ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T;
+  ia.mode = mode; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
   dim3 grid((e->LP / 2 + 255) / 256, MP);
   hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
@@ -743,35 +778,39 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_steps: no sampling call in progress");
   hipStream_t st = (hipStream_t)stream;
   SampleState& s = e->smp;
-  const int n = s.n, MP = s.MP, L = e->L;
+  const int n = s.n, L = e->L;
   const size_t nL = (size_t)n * L;
   for (int done = 0; done < count && s.i_next >= 1; ++done, --s.i_next) {
     const int i = s.i_next;
+    const int na = e->smp_nact[i];                 // active prefix at this step
+    if (na == 0) continue;
+    const int MP = round_up(na, BM);
     {
       GemmArgs a{};
       a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
       HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
-                                                  Prof{e, PC_FWD_L0, 2.0 * n * (double)e->W * (e->L + e->T)})));
+                                                  Prof{e, PC_FWD_L0, 2.0 * na * (double)e->W * (e->L + e->T)})));
     }
-    int rc = hidden_forward(e, MP, n, st);
+    int rc = hidden_forward(e, MP, na, st);
     if (rc) return rc;
     {
       GemmArgs a{};
       a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
       a.rows_valid = MP; a.cols_valid = e->LP;
       HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
-                                                        Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W})));
+                                                        Prof{e, PC_FWD_OUT, 2.0 * na * (double)e->L * e->W})));
     }
     ReverseArgs ra{};
     ra.X = e->X; ra.Y = e->Y; ra.U = e->U;
     ra.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
     ra.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
     ra.Tj = s.multires ? e->Tj_dev : nullptr;
-    ra.n = n; ra.L = L; ra.LP = e->LP; ra.K0 = e->K0; ra.step_i = i; ra.nd = s.nd;
+    ra.rowid = s.multires ? e->rowid_dev : nullptr;
+    ra.n = na; ra.L = L; ra.LP = e->LP; ra.K0 = e->K0; ra.step_i = i; ra.nd = s.nd;
     reverse_coeffs(e, i, ra.c1, ra.sqrt_alpha, ra.sqrt_beta);
     ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
     ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
-    hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, n), dim3(256), 0, st, ra);
+    hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, na), dim3(256), 0, st, ra);
     HIP_TRY(e, hipGetLastError());
   }
   return SDRM_OK;
@@ -784,7 +823,7 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
   if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
   hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
-                     e->smp.n, e->L);
+                     e->smp.n, e->L, (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
   HIP_TRY(e, hipGetLastError());
   e->smp.active = false;
   return SDRM_OK;
