@@ -148,15 +148,28 @@ struct EmbTabArgs {
   int L, W, T, LP, WP, K0;
 };
 
-__device__ __forceinline__ float dot_unrolled(const float* __restrict__ x, const float* __restrict__ y, int n) {
+// sum_t x[t*sx] * y[t*sy]: the table kernels are pure latency chains, so each batch issues 16 + 16
+// independent loads before the first FMA needs one (a handful of memory round trips instead of n/4).
+__device__ __forceinline__ float dot_strided(const float* __restrict__ x, long sx, const float* __restrict__ y, long sy,
+                                             int n) {
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = 0;
-  for (; i + 3 < n; i += 4) {   // four independent load pairs in flight
-    s0 = fmaf(x[i], y[i], s0); s1 = fmaf(x[i + 1], y[i + 1], s1);
-    s2 = fmaf(x[i + 2], y[i + 2], s2); s3 = fmaf(x[i + 3], y[i + 3], s3);
+  int t = 0;
+  for (; t + 16 <= n; t += 16) {
+    float xv[16], yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { xv[u] = x[(t + u) * sx]; yv[u] = y[(t + u) * sy]; }
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      s0 = fmaf(xv[u], yv[u], s0); s1 = fmaf(xv[u + 1], yv[u + 1], s1);
+      s2 = fmaf(xv[u + 2], yv[u + 2], s2); s3 = fmaf(xv[u + 3], yv[u + 3], s3);
+    }
   }
-  for (; i < n; ++i) s0 = fmaf(x[i], y[i], s0);
+  for (; t < n; ++t) s0 = fmaf(x[t * sx], y[t * sy], s0);
   return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ float dot_unrolled(const float* __restrict__ x, const float* __restrict__ y, int n) {
+  return dot_strided(x, 1, y, 1, n);
 }
 
 __global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
@@ -338,17 +351,11 @@ __global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
   const int wlo = (a.W * part) / 16, whi = (a.W * (part + 1)) / 16;
   for (int j0 = 0; j0 < a.T; j0 += 64) {
     const int j = j0 + jj;
-    float s0 = 0.f, s1 = 0.f;
-    if (j < a.T) {
-      int w = wlo;
-      for (; w + 1 < whi; w += 2) {
-        s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
-        s1 = fmaf(a.dC0T[(size_t)(w + 1) * a.TP + t], a.W0[(size_t)(w + 1) * ldw + a.L + j], s1);
-      }
-      if (w < whi) s0 = fmaf(a.dC0T[(size_t)w * a.TP + t], a.W0[(size_t)w * ldw + a.L + j], s0);
-    }
+    float s0 = 0.f;
+    if (j < a.T)
+      s0 = dot_strided(a.dC0T + (size_t)wlo * a.TP + t, a.TP, a.W0 + (size_t)wlo * ldw + a.L + j, ldw, whi - wlo);
     __syncthreads();
-    red[part][jj] = s0 + s1;
+    red[part][jj] = s0;
     __syncthreads();
     if (part == 0 && j < a.T) {
       float s = 0.f;
@@ -363,30 +370,13 @@ __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
   const int n1 = a.W * a.T, n2 = a.T * a.T, n3 = a.T;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nt = a.T + 1;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n1) {
     const int w = i / a.T, j = i - w * a.T;
-    const float* dc = a.dC0T + (size_t)w * a.TP;
-    const float* ec = a.Etab + j;
-    int t = 0;
-    for (; t + 3 < nt; t += 4) {
-      s0 = fmaf(dc[t], ec[(size_t)t * a.T], s0); s1 = fmaf(dc[t + 1], ec[(size_t)(t + 1) * a.T], s1);
-      s2 = fmaf(dc[t + 2], ec[(size_t)(t + 2) * a.T], s2); s3 = fmaf(dc[t + 3], ec[(size_t)(t + 3) * a.T], s3);
-    }
-    for (; t < nt; ++t) s0 = fmaf(dc[t], ec[(size_t)t * a.T], s0);
-    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = (s0 + s1) + (s2 + s3);
+    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = dot_strided(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, nt);
   } else if (i < n1 + n2) {
     const int k = i - n1;
     const int j = k / a.T, ii = k - j * a.T;
-    const float* de = a.dE + j;
-    const float* te = a.temb + ii;
-    int t = 0;
-    for (; t + 3 < nt; t += 4) {
-      s0 = fmaf(de[(size_t)t * a.T], te[(size_t)t * a.T], s0); s1 = fmaf(de[(size_t)(t + 1) * a.T], te[(size_t)(t + 1) * a.T], s1);
-      s2 = fmaf(de[(size_t)(t + 2) * a.T], te[(size_t)(t + 2) * a.T], s2); s3 = fmaf(de[(size_t)(t + 3) * a.T], te[(size_t)(t + 3) * a.T], s3);
-    }
-    for (; t < nt; ++t) s0 = fmaf(de[(size_t)t * a.T], te[(size_t)t * a.T], s0);
-    a.g[a.off_we + k] = (s0 + s1) + (s2 + s3);
+    a.g[a.off_we + k] = dot_strided(a.dE + j, a.T, a.temb + ii, a.T, nt);
   } else if (i < n1 + n2 + n3) {
     const int j = i - n1 - n2;
     float s = 0.f;
