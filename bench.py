@@ -164,6 +164,9 @@ def main():
     ap.add_argument("--steps", type=int, default=186)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,11 +175,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if args.share_gpu else local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from sdrm_amd.engine import Engine
     from sdrm_amd.parallel import ShardedTrainer, shard_rows
@@ -194,7 +197,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -261,7 +267,9 @@ def main():
             "config": {"workload": wl["name"], "latent": L, "width": W, "timesteps": T, "hidden_layers": H,
                        "global_batch": B, "n_sample": n, "step_mix": f"{n_train} train : {T} sample per job cycle",
                        "timed_train_steps": kinds["train"], "timed_sample_steps": kinds["sample"],
-                       "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}"},
+                       "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
+                       "collectives": (f"{args.backend}: all-reduce of 5 f64 loss sums + flat f32 gradient per train step"
+                                       if world > 1 else "none")},
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
             "roofline": roof,

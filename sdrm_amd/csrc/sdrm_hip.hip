@@ -18,7 +18,8 @@ using namespace sdrm;
 
 namespace {
 
-constexpr int BM = 128, BN = 128;   // row padding granule / reference tile for split sizing
+constexpr int BM = 64, BN = 64;     // row padding granule = rows of the default tile (the 128-row alternates read into
+                                    // the slack every buffer carries, and write rows nobody reads)
 constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
 constexpr int TARGET_BLOCKS = 1024; // work-groups a wgrad launch aims for (4 per CU)
 constexpr int LOSS_BLOCKS = 256;
@@ -380,7 +381,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
-  e->MPmax = round_up(3 * max_rows, BM);
+  e->MPmax = round_up(3 * max_rows, 128);
   int64_t o = 0;
   e->off_we = o; o += (int64_t)T * T;
   e->off_be = o; o += T;
