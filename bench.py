@@ -140,6 +140,46 @@ def cpu_baseline(wl, seconds_budget=25.0):
                       f"same 15:78 mix, oracle/sdrm_oracle.py on torch CPU ops, {cores} threads, {dt:.1f} s"}
 
 
+OTHER = {   # BASELINE.json configs besides the benched one (README hyper-parameters)
+    "ML-100k/SVD  B=550 L=830 T=83 H=2 n=843": dict(L=830, W=830, T=83, H=2, B=550, n=843),
+    "ML-1M/MLP    B=160 L=340 T=78 H=1 n=5429 (README batch)": dict(L=340, W=340, T=78, H=1, B=160, n=5429),
+    "ADM/NeuMF    B=850 L=40 T=93 H=5 n=9558": dict(L=40, W=40, T=93, H=5, B=850, n=9558),
+}
+
+
+def other_configs():
+    from sdrm_amd.engine import Engine
+    res = {}
+    for name, c in OTHER.items():
+        eng = Engine(c["L"], c["W"], c["T"], c["H"], max_rows=max(c["B"], c["n"]))
+        eng.set_params(synth.flatten_params(synth.init_params(c["L"], c["W"], c["T"], c["H"], seed=1), c["H"]))
+        x0 = torch.from_numpy(synth.synth_latents(c["B"], c["L"], seed=0)).cuda()
+        entry = {}
+        for kind in ("train", "sample_full", "sample_multires"):
+            if kind == "train":
+                fn, reps = (lambda: eng.train_step(x0, 1e-5, seed=1, step=3)), 100
+            else:
+                eng.sample_begin(c["n"], seed=2, call_id=1, multires=(kind == "sample_multires"))
+                left = [c["T"]]
+
+                def fn():
+                    if eng.sample_steps(1) == 0:
+                        eng.sample_end()
+                        eng.sample_begin(c["n"], seed=2, call_id=1, multires=(kind == "sample_multires"))
+                reps = 2 * c["T"]
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            entry[kind + "_steps_per_s"] = round(reps / (time.perf_counter() - t0), 1)
+        eng.close()
+        res[name] = entry
+    return res
+
+
 def pmc_traffic(kernel_class: str):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json,
     made by tools/pmc_summary.py from two separate `rocprofv3 --pmc` runs of this same command; gfx950
@@ -164,6 +204,8 @@ def main():
     ap.add_argument("--steps", type=int, default=186)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-configs", action="store_true",
+                    help="also time the other BASELINE.json configs (train and sample steps/s each); extra fields only")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
@@ -274,6 +316,8 @@ def main():
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
             "roofline": roof,
         }
+        if world == 1 and args.other_configs:
+            out["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
