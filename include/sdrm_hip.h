@@ -174,6 +174,9 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
+/* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
+ * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
+int sdrm_debug_set_skinny(int on);
 /* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, -1 = default);
  * also env SDRM_TILE.  Tuning aid. */
 int sdrm_debug_set_tile(int cfg);

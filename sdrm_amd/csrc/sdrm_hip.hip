@@ -13,6 +13,7 @@
 #include "../../include/sdrm_hip.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "skinny.h"
 
 using namespace sdrm;
 
@@ -48,6 +49,7 @@ struct sdrm_engine {
   int *tdev = nullptr;
   int64_t *Tj_dev = nullptr;
   int *rowid_dev = nullptr;
+  float *rev_dev = nullptr;          // [3][T+1] reverse-step coefficients c1, sqrt(alpha), sqrt(beta)
   std::vector<int> smp_nact, smp_perm;
   std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
   std::vector<float> h_beta, h_alpha, h_alphabar;
@@ -60,7 +62,8 @@ struct sdrm_engine {
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
-  } smp = {false, 0, 0, 0, 0, 0, 1.f, nullptr, nullptr, 0, 0, 0};
+    const float* xT; bool skinny; bool skinny_launched; int i_start;
+  } smp = {false, 0, 0, 0, 0, 0, 1.f, nullptr, nullptr, 0, 0, 0, nullptr, false, false, 0};
   // event profiling (bench only)
   bool prof_on = false;
   int prof_cap = 0;
@@ -125,6 +128,7 @@ constexpr int N_TILE_CFGS = 4;
 const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128};
 const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128};
 int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
+int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
 
 int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
   return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
@@ -327,6 +331,15 @@ int upload_schedule(sdrm_engine* e, float beta1, float beta2) {
   HIP_TRY(e, hipMemcpy(e->sched + 2 * n, ab.data(), n * 4, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(e->sched + 3 * n, sq.data(), n * 4, hipMemcpyHostToDevice));
   HIP_TRY(e, hipMemcpy(e->sched + 4 * n, om.data(), n * 4, hipMemcpyHostToDevice));
+  if (e->rev_dev) {   // (1-alpha)/sqrt(1-alphabar), sqrt(alpha), sqrt(beta) per step, fp32 like the reference (:23-24)
+    std::vector<float> rev(3 * (size_t)n, 0.f);
+    for (int i = 1; i < n; ++i) {
+      rev[i] = (1.f - al[i]) / std::sqrt(1.f - ab[i]);
+      rev[n + i] = std::sqrt(al[i]);
+      rev[2 * n + i] = std::sqrt(b[i]);
+    }
+    HIP_TRY(e, hipMemcpy(e->rev_dev, rev.data(), rev.size() * 4, hipMemcpyHostToDevice));
+  }
   return SDRM_OK;
 }
 
@@ -357,6 +370,11 @@ void reverse_coeffs(const sdrm_engine* e, int i, float& c1, float& sa, float& sb
 
 // =================================================================================================
 extern "C" {
+
+int sdrm_debug_set_skinny(int on) {
+  g_skinny = on ? 1 : 0;
+  return SDRM_OK;
+}
 
 int sdrm_debug_set_tile(int cfg) {
   g_force_cfg = cfg;
@@ -409,6 +427,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->Woc, (size_t)round_up(e->LP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
+  HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
   HIP_TRY(e, dalloc(&e->dA, MP * e->WP)); HIP_TRY(e, dalloc(&e->dB, MP * e->WP));
@@ -437,7 +456,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->dB, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -762,6 +781,11 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
       HIP_TRY(e, hipMemcpyAsync(Tj_out, e->smp_tj_orig.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     }
   }
+  const bool skinny = g_skinny && e->LP <= 64 && e->WP <= 64;
+  if (skinny) {
+    e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, true, false, i_start};
+    return SDRM_OK;
+  }
   SampleInitArgs ia{};
   ia.xT = xT; ia.keep = keep; ia.Tj = multires ? e->Tj_dev : nullptr; ia.rowid = multires ? e->rowid_dev : nullptr;
   ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T;
@@ -770,7 +794,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   dim3 grid((e->LP / 2 + 255) / 256, MP);
   hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
   HIP_TRY(e, hipGetLastError());
-  e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0};
+  e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, false, false, i_start};
   return SDRM_OK;
 }
 
@@ -781,6 +805,42 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   SampleState& s = e->smp;
   const int n = s.n, L = e->L;
   const size_t nL = (size_t)n * L;
+  if (s.skinny) {
+    // One persistent launch runs the whole reverse loop (rows are independent across all timesteps); the
+    // step counter is then only book-keeping for the resumable API.
+    if (!s.skinny_launched) {
+      SkinnyArgs ka{};
+      ka.W0c = e->W0c; ka.K0 = e->K0; ka.Whc = e->Whc; ka.Woc = e->Woc; ka.bh = e->bhc; ka.bo = e->boc;
+      ka.B0tab = e->B0tab; ka.slope0 = slope_ptr(e, 0); ka.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
+      ka.rev = e->rev_dev; ka.xT = s.xT; ka.Z = s.z; ka.keep = s.keep;
+      ka.Tj = s.multires ? e->Tj_dev : nullptr; ka.rowid = s.multires ? e->rowid_dev : nullptr;
+      ka.out = e->X; ka.n = n; ka.L = L; ka.W = e->W; ka.T = e->T; ka.H = e->H;
+      ka.mode = s.mode; ka.seed_lo = (uint32_t)s.seed; ka.seed_hi = (uint32_t)(s.seed >> 32);
+      ka.call_id = (uint32_t)s.call_id; ka.row0 = s.row0; ka.nd = s.nd;
+      const int NL = e->LP / 16, NW = e->WP / 16;
+      const int LD0 = e->LP + 4, LDH = e->WP + 4, SCR = (e->LP > e->WP ? e->LP : e->WP) + 4;
+      const size_t lds = (size_t)(e->WP * LD0 + e->WP * LDH + e->LP * LDH + 4 * 16 * SCR) * sizeof(float);
+      dim3 grid((n + 63) / 64);
+      hipError_t rc = hipSuccess;
+#define SKINNY_LAUNCH(nl, nw)                                                                                   \
+  do {                                                                                                          \
+    rc = hipFuncSetAttribute((const void*)k_skinny_sample<nl, nw>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (rc == hipSuccess) {                                                                                     \
+      hipLaunchKernelGGL((k_skinny_sample<nl, nw>), grid, dim3(256), lds, st, ka);                              \
+      rc = hipGetLastError();                                                                                   \
+    }                                                                                                           \
+  } while (0)
+      if (NL == 2 && NW == 2) SKINNY_LAUNCH(2, 2);
+      else if (NL == 2 && NW == 4) SKINNY_LAUNCH(2, 4);
+      else if (NL == 4 && NW == 2) SKINNY_LAUNCH(4, 2);
+      else SKINNY_LAUNCH(4, 4);
+#undef SKINNY_LAUNCH
+      HIP_TRY(e, rc);
+      s.skinny_launched = true;
+    }
+    s.i_next = s.i_next > count ? s.i_next - count : 0;
+    return SDRM_OK;
+  }
   for (int done = 0; done < count && s.i_next >= 1; ++done, --s.i_next) {
     const int i = s.i_next;
     const int na = e->smp_nact[i];                 // active prefix at this step
@@ -823,8 +883,11 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (!e || !out) return SDRM_ERR_ARG;
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
   if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
-  hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
-                     e->smp.n, e->L, (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
+  if (e->smp.skinny)   // the persistent kernel wrote dense [n,L] rows in original order
+    HIP_TRY(e, hipMemcpyAsync(out, e->X, (size_t)e->smp.n * e->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  else
+    hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
+                       e->smp.n, e->L, (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
   HIP_TRY(e, hipGetLastError());
   e->smp.active = false;
   return SDRM_OK;

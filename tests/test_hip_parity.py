@@ -39,6 +39,17 @@ def engine_cls():
     return Engine
 
 
+@pytest.fixture(params=["skinny", "gemm"])
+def sampler_path(request):
+    """Narrow nets (padded widths <= 64) sample through the persistent LDS-resident kernel (csrc/skinny.h) by
+    default; run every sampling parity test through it and through the general per-layer GEMM path."""
+    from sdrm_amd import _lib
+    lib = _lib.load()
+    lib.sdrm_debug_set_skinny(1 if request.param == "skinny" else 0)
+    yield request.param
+    lib.sdrm_debug_set_skinny(1)
+
+
 def per_tensor(flat, dims):
     L, W, T, H = dims
     shapes = synth.param_shapes(L, W, T, H)
@@ -155,7 +166,7 @@ def test_train_golden(engine_cls, golden):
         e.close()
 
 
-def test_sampling_golden(engine_cls, golden):
+def test_sampling_golden(engine_cls, golden, sampler_path):
     g = golden("sampling")
     for ci in range(int(g["n_cases"])):
         pf = f"c{ci}_"
@@ -290,7 +301,7 @@ def test_philox_mode_train(engine_cls, dims):
 
 
 @pytest.mark.parametrize("multires", [False, True])
-def test_philox_mode_sampling(engine_cls, multires):
+def test_philox_mode_sampling(engine_cls, multires, sampler_path):
     from oracle import philox_ref as pr
     from oracle import sdrm_oracle as orc
     L, W, T, H, n = 37, 40, 12, 2, 19
@@ -310,6 +321,22 @@ def test_philox_mode_sampling(engine_cls, multires):
     assert close(out, explicit.cpu().numpy(), 2e-5)
     ref = orc.Oracle(L, W, T, H, init).sample(xT, z, keep, Tj)
     assert close(out, ref.numpy())
+    e.close()
+
+
+@pytest.mark.parametrize("dims", [(40, 40, 93, 5, 300), (20, 64, 11, 0, 70), (64, 24, 9, 1, 33)])
+@pytest.mark.parametrize("multires", [False, True])
+def test_skinny_sampler_vs_oracle(engine_cls, dims, multires):
+    """The persistent sampler at the ADM shape (and both rectangular paddings) against the CPU oracle, explicit randoms."""
+    from oracle import sdrm_oracle as orc
+    L, W, T, H, n = dims
+    init = synth.init_params(L, W, T, H, seed=21)
+    xT, z, keep, Tj = synth.synth_sample_randoms(n, L, T, 0.8, seed=22, multires=multires)
+    e = engine_cls(L, W, T, H, n)
+    e.set_params(synth.flatten_params(init, H))
+    out = e.sample(n, nd=0.8, multires=multires, xT=xT, z=z, keep=keep, Tj=Tj if multires else None)
+    ref = orc.Oracle(L, W, T, H, init).sample(xT, z, keep, Tj if multires else None)
+    assert close(out, ref.numpy()), rel_max(out.cpu().numpy(), ref.numpy())
     e.close()
 
 
