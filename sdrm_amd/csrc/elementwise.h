@@ -292,7 +292,8 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   }
   const double N = a.sums[4];
   const double A = a.sums[0] / N, C = a.sums[1] / N, Rbar = a.sums[2] / N;
-  const double V = (a.sums[3] - N * Rbar * Rbar) / (N - 1.0);
+  // unbiased variance; a single element gives 0/0 = NaN exactly as torch.var does (train_SDRM.py:198)
+  const double V = (N > 1.0) ? (a.sums[3] - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
   const double den = 1e-8 + V;
   const double k = 0.5 / den;
   if (r == 0 && c == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);

@@ -385,6 +385,39 @@ def test_sharded_equals_single(engine_cls):
     ref.close()
 
 
+@pytest.mark.parametrize("dims", [(1, 1, 2, 0, 1), (33, 65, 3, 16, 2), (1000, 1000, 198, 5, 30), (20, 1000, 8, 1, 1000),
+                                  (1000, 20, 3, 0, 31)])
+def test_envelope_corners_vs_oracle(engine_cls, dims):
+    """Corners of the shape envelope (hyperparameter_search.py:103-113: L,W in 20..1000, T in 3..198, H in 0..5,
+    B in 30..1000; plus degenerate 1-wide / 1-row cases): forward outputs, loss and a 2-step parameter trajectory."""
+    from oracle import sdrm_oracle as orc
+    L, W, T, H, B = dims
+    init = synth.init_params(L, W, T, H, seed=31)
+    x0 = synth.synth_latents(B, L, seed=32)
+    o = orc.Oracle(L, W, T, H, init)
+    e = engine_cls(L, W, T, H, B)
+    e.set_params(synth.flatten_params(init, H))
+    for step in range(2 if B * L > 1 else 1):   # a 1-element batch has var(R) = 0/0: NaN loss in the reference too
+        eps, t, masks = synth.synth_train_randoms(B, L, T, 1.0, seed=33 + step)
+        loss_ref, _, outs_ref = o.train_step(x0, eps, t, list(masks), 1e-4)
+        loss = e.train_step(x0, 1e-4, noise=eps, t=t, keep=masks)
+        psq = e.train_outputs(B).cpu().numpy()
+        for j in range(3):
+            assert close(psq[j], outs_ref[j].numpy(), 2e-4), (step, j)
+        if B * L > 1:   # var(R) of a single element is 0/0 in the reference too
+            assert abs(float(loss.cpu()) - loss_ref) <= 2e-4 * abs(loss_ref), (step, float(loss.cpu()), loss_ref)
+    if B * L > 1:
+        assert rel_l2(e.get_params().cpu().numpy(), o.flat(synth.param_names(H))) <= TOL
+    if B * L == 1:
+        assert np.isnan(float(loss.cpu())) and np.isnan(loss_ref)
+        o = orc.Oracle(L, W, T, H, init)
+        e.set_params(synth.flatten_params(init, H))
+    xT, z, keep, _ = synth.synth_sample_randoms(min(B, 50), L, T, 1.0, seed=40)
+    got = e.sample(min(B, 50), xT=xT, z=z, keep=keep)
+    assert close(got, o.sample(xT, z, keep).numpy(), 2e-4)
+    e.close()
+
+
 def test_error_behaviour(engine_cls):
     from sdrm_amd.engine import SdrmError
     e = engine_cls(16, 16, 5, 1, 4)
