@@ -12,6 +12,66 @@ constexpr float MU = 0.1f;          // score_matching_loss(..., mu=.1), :333
 constexpr float MU2 = 0.01f;        // mu ** 2, :196
 
 // ---------------------------------------------------------------------------------------------
+// Per-step time-embedding tables (only T+1 distinct timesteps exist, SURVEY a4):
+//   E[t]  = temb[t] * We^T + be                    (:98-99)
+//   C0[t] = E[t] * W0[:, L:]^T                     (the emb part of dnn.0, :101-102)
+// written as C0^T into the trailing columns of the padded layer-0 weight W0c[w][LP + t]; for sampling
+// (all rows share t) also B0tab[t][w] = b0[w] + C0[t][w].
+struct EmbTabArgs {
+  const float* temb; const float* We; const float* be; const float* W0; const float* b0;
+  float* Etab; float* W0c; float* B0tab;
+  int L, W, T, LP, WP, K0;
+};
+
+// sum_t x[t*sx] * y[t*sy]: the table kernels are pure latency chains, so each batch issues 16 + 16
+// independent loads before the first FMA needs one (a handful of memory round trips instead of n/4).
+__device__ __forceinline__ float dot_strided(const float* __restrict__ x, long sx, const float* __restrict__ y, long sy,
+                                             int n) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int t = 0;
+  for (; t + 16 <= n; t += 16) {
+    float xv[16], yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { xv[u] = x[(t + u) * sx]; yv[u] = y[(t + u) * sy]; }
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      s0 = fmaf(xv[u], yv[u], s0); s1 = fmaf(xv[u + 1], yv[u + 1], s1);
+      s2 = fmaf(xv[u + 2], yv[u + 2], s2); s3 = fmaf(xv[u + 3], yv[u + 3], s3);
+    }
+  }
+  for (; t < n; ++t) s0 = fmaf(x[t * sx], y[t * sy], s0);
+  return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ float dot_unrolled(const float* __restrict__ x, const float* __restrict__ y, int n) {
+  return dot_strided(x, 1, y, 1, n);
+}
+
+__device__ __forceinline__ void emb_tables_row(const EmbTabArgs& a, int t, float* sh /* [2*T] */) {
+  float* tr = sh;
+  float* er = sh + a.T;
+  for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
+    const float s = a.be[j] + dot_unrolled(a.We + (size_t)j * a.T, tr, a.T);
+    er[j] = s;
+    a.Etab[(size_t)t * a.T + j] = s;
+  }
+  __syncthreads();
+  const int ldw = a.L + a.T;
+  for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
+    const float s = (w < a.W) ? dot_unrolled(a.W0 + (size_t)w * ldw + a.L, er, a.T) : 0.f;
+    a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
+    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
+  extern __shared__ float sh[];  // [2*T]: temb row, E row
+  emb_tables_row(a, blockIdx.x, sh);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Train-step staging: q_sample (:203) + the three dropout-ed inputs (:100) + one-hot(t) columns.
 //   U[0*B + r] = 2*keep1 * (sqrt(abar[t]) x0 + (1-abar[t]) eps)      pass P (:328,:331)
 //   U[1*B + r] = 2*keep2 * x0                                         pass S (:193)
@@ -24,10 +84,17 @@ struct PrepTrainArgs {
   float* U; int* tdev;
   int B, L, LP, K0, T, MP;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
+  EmbTabArgs emb; int emb_row0;   // grid rows >= emb_row0 build the step's embedding tables (independent work,
+                                  // merged here so it runs beside the staging instead of as its own launch)
 };
 
 __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
+  extern __shared__ float sh[];
   const int r = blockIdx.y;
+  if (r >= a.emb_row0) {
+    if (blockIdx.x == 0) emb_tables_row(a.emb, r - a.emb_row0, sh);
+    return;
+  }
   const int q = blockIdx.x * 256 + threadIdx.x;  // column pair
   const int c = 2 * q;
   if (c >= a.K0) return;
@@ -134,63 +201,6 @@ __global__ __launch_bounds__(256) void k_prep_forward(const PrepFwdArgs a) {
     }
   }
   *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = o;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-step time-embedding tables (only T+1 distinct timesteps exist, SURVEY a4):
-//   E[t]  = temb[t] * We^T + be                    (:98-99)
-//   C0[t] = E[t] * W0[:, L:]^T                     (the emb part of dnn.0, :101-102)
-// written as C0^T into the trailing columns of the padded layer-0 weight W0c[w][LP + t]; for sampling
-// (all rows share t) also B0tab[t][w] = b0[w] + C0[t][w].
-struct EmbTabArgs {
-  const float* temb; const float* We; const float* be; const float* W0; const float* b0;
-  float* Etab; float* W0c; float* B0tab;
-  int L, W, T, LP, WP, K0;
-};
-
-// sum_t x[t*sx] * y[t*sy]: the table kernels are pure latency chains, so each batch issues 16 + 16
-// independent loads before the first FMA needs one (a handful of memory round trips instead of n/4).
-__device__ __forceinline__ float dot_strided(const float* __restrict__ x, long sx, const float* __restrict__ y, long sy,
-                                             int n) {
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int t = 0;
-  for (; t + 16 <= n; t += 16) {
-    float xv[16], yv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { xv[u] = x[(t + u) * sx]; yv[u] = y[(t + u) * sy]; }
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) {
-      s0 = fmaf(xv[u], yv[u], s0); s1 = fmaf(xv[u + 1], yv[u + 1], s1);
-      s2 = fmaf(xv[u + 2], yv[u + 2], s2); s3 = fmaf(xv[u + 3], yv[u + 3], s3);
-    }
-  }
-  for (; t < n; ++t) s0 = fmaf(x[t * sx], y[t * sy], s0);
-  return (s0 + s1) + (s2 + s3);
-}
-
-__device__ __forceinline__ float dot_unrolled(const float* __restrict__ x, const float* __restrict__ y, int n) {
-  return dot_strided(x, 1, y, 1, n);
-}
-
-__global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
-  extern __shared__ float sh[];  // [2*T]: temb row, E row
-  const int t = blockIdx.x;
-  float* tr = sh;
-  float* er = sh + a.T;
-  for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
-  __syncthreads();
-  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
-    const float s = a.be[j] + dot_unrolled(a.We + (size_t)j * a.T, tr, a.T);
-    er[j] = s;
-    a.Etab[(size_t)t * a.T + j] = s;
-  }
-  __syncthreads();
-  const int ldw = a.L + a.T;
-  for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
-    const float s = (w < a.W) ? dot_unrolled(a.W0 + (size_t)w * ldw + a.L, er, a.T) : 0.f;
-    a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
-    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : 0.f;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -333,9 +343,9 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
 // ---------------------------------------------------------------------------------------------
 // Embedding-path backward.  k_grad_finalize first reduces the one-hot columns of the layer-0 weight
 // gradient slabs into a dense dC0T[w][t] = sum over rows with timestep t of dpre0[row][w]  ([W][TP]).
-//   k_emb_bwd1:  dE[t][j]   = sum_w dC0T[w][t] * W0[w][L+j]
-//   k_emb_bwd2:  dW0[w][L+j] = sum_t dC0T[w][t] * E[t][j]
-//                dWe[j][i]  = sum_t dE[t][j] * temb[t][i] ;  dbe[j] = sum_t dE[t][j]
+//   k_emb_bwd1:  dE[t][j]   = sum_w dC0T[w][t] * W0[w][L+j]   and (independent, extra blocks)
+//                dW0[w][L+j] = sum_t dC0T[w][t] * E[t][j]
+//   k_emb_bwd2:  dWe[j][i]  = sum_t dE[t][j] * temb[t][i] ;  dbe[j] = sum_t dE[t][j]
 struct EmbBwdArgs {
   const float* dC0T; int TP;
   const float* W0; const float* Etab; const float* temb;
@@ -343,9 +353,18 @@ struct EmbBwdArgs {
   int L, W, T;
 };
 
-// 1024 threads = 16 w-slices x 64 j-lanes; the slices meet in LDS.
+// Blocks [0, T]: dE row t (1024 threads = 16 w-slices x 64 j-lanes; the slices meet in LDS).
+// Blocks beyond: the independent product dW0[:, L:] = dC0^T * E, 1024 outputs per block.
 __global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
   __shared__ float red[16][64];
+  if ((int)blockIdx.x > a.T) {
+    const int i = ((int)blockIdx.x - a.T - 1) * 1024 + threadIdx.x;
+    if (i < a.W * a.T) {
+      const int w = i / a.T, j = i - w * a.T;
+      a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = dot_strided(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, a.T + 1);
+    }
+    return;
+  }
   const int t = blockIdx.x;
   const int jj = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int ldw = a.L + a.T;
@@ -368,13 +387,10 @@ __global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
-  const int n1 = a.W * a.T, n2 = a.T * a.T, n3 = a.T;
+  const int n1 = 0, n2 = a.T * a.T, n3 = a.T;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nt = a.T + 1;
-  if (i < n1) {
-    const int w = i / a.T, j = i - w * a.T;
-    a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = dot_strided(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, nt);
-  } else if (i < n1 + n2) {
+  if (i < n1 + n2) {
     const int k = i - n1;
     const int j = k / a.T, ii = k - j * a.T;
     a.g[a.off_we + k] = dot_strided(a.dE + j, a.T, a.temb + ii, a.T, nt);

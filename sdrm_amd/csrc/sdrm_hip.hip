@@ -287,11 +287,16 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
   return SDRM_OK;
 }
 
-int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
+EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
   EmbTabArgs a{};
   a.temb = e->temb; a.We = e->p + e->off_we; a.be = e->p + e->off_be; a.W0 = e->p + e->off_w0; a.b0 = e->p + e->off_b0;
   a.Etab = e->Etab; a.W0c = e->W0c; a.B0tab = for_sampling ? e->B0tab : nullptr;
   a.L = e->L; a.W = e->W; a.T = e->T; a.LP = e->LP; a.WP = e->WP; a.K0 = e->K0;
+  return a;
+}
+
+int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
+  const EmbTabArgs a = emb_args(e, for_sampling);
   hipLaunchKernelGGL(k_emb_tables, dim3(e->T + 1), dim3(256), 2 * e->T * sizeof(float), st, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
@@ -547,19 +552,19 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
   pa.row0 = row0; pa.nd = nd;
   {
-    dim3 grid((e->K0 / 2 + 255) / 256, B + (MP - 3 * B));
-    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 0, st, pa);
+    pa.emb = emb_args(e, false);
+    pa.emb_row0 = B + (MP - 3 * B);
+    dim3 grid((e->K0 / 2 + 255) / 256, pa.emb_row0 + e->T + 1);
+    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 2 * e->T * sizeof(float), st, pa);
     HIP_TRY(e, hipGetLastError());
   }
-  int rc = emb_tables(e, false, st);
-  if (rc) return rc;
   {
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
                                                 Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)})));
   }
-  rc = hidden_forward(e, MP, 3 * B, st);
+  int rc = hidden_forward(e, MP, 3 * B, st);
   if (rc) return rc;
   {
     GemmArgs a{};
@@ -629,10 +634,10 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = e->g;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
-  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1), dim3(1024), 0, st, ea);
+  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 1023) / 1024), dim3(1024), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
   {
-    const int items = e->W * e->T + e->T * e->T + e->T;
+    const int items = e->T * e->T + e->T;
     hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
     HIP_TRY(e, hipGetLastError());
   }
