@@ -177,7 +177,8 @@ const char* sdrm_build_info(void);
 /* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);
-/* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, -1 = default);
+/* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, 4 = 32x32x32 on the 16x16x4 MFMA,
+ * -1 = automatic: 64x64x16, or 32x32x32 when the launch has too few rows to fill the chip);
  * also env SDRM_TILE.  Tuning aid. */
 int sdrm_debug_set_tile(int cfg);
 /* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),

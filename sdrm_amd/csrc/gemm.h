@@ -40,16 +40,26 @@ enum : int {
 
 constexpr int NTHREADS = 256;
 
-template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4, int BK_ = 16>
+// MF = edge of the MFMA output tile: 32 -> v_mfma_f32_32x32x2_f32 (16 accumulator VGPRs per tile), 16 ->
+// v_mfma_f32_16x16x4_f32 (4 VGPRs).  Same flop rate; the 16-wide form lets a 32x32 block tile be split over four
+// waves, which is what a launch with few rows needs: it cannot fill the chip with 64x64 tiles, and a lone block's
+// time is its per-wave chain of dependent MFMAs (K/2 x 64 cycles for a 32x32 tile, K/4 x 32 for a 16x16 one).
+template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4, int BK_ = 16, int MF_ = 32>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, MF = MF_;
   static constexpr int MINW = MINW_;   // waves per SIMD the register allocator must leave room for
-  static constexpr int TM = BM_ / WM_ / 32, TN = BN_ / WN_ / 32;   // MFMA tiles per wave
-  static constexpr int LDA = BM_ + 4, LDB = BN_ + 4;               // LDS row strides (floats)
+  static constexpr int TM = BM_ / WM_ / MF_, TN = BN_ / WN_ / MF_;   // MFMA tiles per wave
+  static constexpr int PADMAX = (MF_ == 32) ? 4 : 16;
+  static constexpr int LDA = BM_ + PADMAX, LDB = BN_ + PADMAX;     // upper bound of the LDS row strides (floats)
   static constexpr int STAGE = BK * (LDA + LDB);                   // floats per pipeline stage
   static_assert(WM_ * WN_ == 4, "4 waves per work-group");
-  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+  static_assert(MF_ == 32 || MF_ == 16, "MFMA tile edge");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one MFMA tile");
 };
+
+template <int MF> struct AccT;
+template <> struct AccT<32> { typedef float type __attribute__((ext_vector_type(16))); };
+template <> struct AccT<16> { typedef float type __attribute__((ext_vector_type(4))); };
 
 struct GemmArgs {
   const float* A; int lda; int limA;   // limA: valid extent of A's output-side index (multiple of 32)
@@ -141,10 +151,16 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
 __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArgs p) {
-  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN;
-  // LDS row strides: +2 floats for transposing (k-contiguous) stores, which makes the 4*kq*LD + i bank pattern
-  // of a half-wave at most 2-way (free) for BK = 16 and 32; +4 keeps ds_write_b128 rows 16-byte aligned.
-  constexpr int LDA = BM + (LOADA == LD_KCONTIG ? 2 : 4), LDB = BN + (LOADB == LD_KCONTIG ? 2 : 4);
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN, MF = Cfg::MF;
+  constexpr int NR = (MF == 32) ? 16 : 4;      // accumulator registers per MFMA tile
+  constexpr int KG = (MF == 32) ? 2 : 4;       // k consumed by one MFMA
+  typedef typename AccT<MF>::type acc_t;
+  // LDS row strides.  32-wide MFMA: +2 floats for transposing (k-contiguous) stores, which makes the 4*kq*LD + i
+  // bank pattern of a half-wave at most 2-way (free) for BK = 16 and 32; +4 keeps ds_write_b128 rows 16-byte
+  // aligned.  16-wide MFMA: a fragment read touches rows k+0..3 at 16 consecutive floats each, conflict-free
+  // when LD = 16 (mod 32).
+  constexpr int LDA = BM + (MF == 16 ? 16 : (LOADA == LD_KCONTIG ? 2 : 4));
+  constexpr int LDB = BN + (MF == 16 ? 16 : (LOADB == LD_KCONTIG ? 2 : 4));
   constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
   static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
@@ -152,7 +168,8 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const int l31 = lane & 31, lhi = lane >> 5;
+  // lane -> (index within the tile edge, k sub-index of the MFMA): 32x32x2 has 32 x 2, 16x16x4 has 16 x 4
+  const int l31 = (MF == 32) ? (lane & 31) : (lane & 15), lhi = (MF == 32) ? (lane >> 5) : (lane >> 4);
 
   int logical, split;
   if (EPI == EPI_SLAB) {
@@ -175,13 +192,13 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   const float slopeA = (XFA == XF_PRELU) ? *p.slopeA : 0.f;
   const float slopeB = (XFB == XF_PRELU) ? *p.slopeB : 0.f;
 
-  f32x16 acc[TM][TN];
+  acc_t acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < NR; ++r) acc[a][b][r] = 0.f;
 
   // Two register sets hold the K-steps i+1 and i+2 while step i is multiplied out of LDS: every global
   // load has two full K-steps to land (an HBM round trip is longer than one 16-deep step of MFMAs).
@@ -216,9 +233,9 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     const float* Bs = As + BK * LDA;
     if (wave_active) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + 32 * a];
+      for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + MF * a];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + 32 * b];
+      for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + MF * b];
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -229,20 +246,22 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
       // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
 #pragma unroll
-      for (int s = 0; s < BK / 2; ++s) {
+      for (int s = 0; s < BK / KG; ++s) {
         const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < BK / 2) {
+        if (s + 1 < BK / KG) {
 #pragma unroll
-          for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + 2 * (s + 1) * LDA + 32 * a];
+          for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + KG * (s + 1) * LDA + MF * a];
 #pragma unroll
-          for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + 2 * (s + 1) * LDB + 32 * b];
+          for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + KG * (s + 1) * LDB + MF * b];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b) {
+            if constexpr (MF == 32) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -281,8 +300,10 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 #endif
 
   // ------------------------------------------------------------------ epilogue
-  // accumulator register r of tile (a,b): row = m0 + wm*(BM/WM) + a*32 + (r&3) + 8*(r>>2) + 4*lhi,
-  //                                        col = n0 + wn*(BN/WN) + b*32 + l31
+  // accumulator register r of tile (a,b), 32-wide: row = m0 + wm*(BM/WM) + a*32 + (r&3) + 8*(r>>2) + 4*lhi,
+  //                                                 col = n0 + wn*(BN/WN) + b*32 + l31
+  //                                        16-wide: row = ... + a*16 + 4*lhi + r ; col = ... + b*16 + l31
+  auto rowoff = [](int r) { return (MF == 32) ? (r & 3) + 8 * (r >> 2) : r; };
   float slope_sum = 0.f;
   const float slopeE = (EPI == EPI_DPRELU) ? *p.slopeE : 0.f;
   float* __restrict__ Cp = p.C;
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int tm0 = m0 + wm * (BM / Cfg::WM) + a * 32, tn0 = n0 + wn * (BN / Cfg::WN) + b * 32;
+      const int tm0 = m0 + wm * (BM / Cfg::WM) + a * MF, tn0 = n0 + wn * (BN / Cfg::WN) + b * MF;
       __builtin_amdgcn_sched_barrier(0);   // one tile's addresses live at a time (keeps the kernel at <=128 VGPRs)
       if (tm0 >= p.limA || tn0 >= p.limB) continue;  // wave-uniform: tile entirely outside the matrix
       const int col = tn0 + l31;
@@ -299,24 +320,24 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
           Cp[(size_t)row * p.ldc + col] = acc[a][b][r] + bias;
         }
       } else if (EPI == EPI_BIAS_TANH) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
           if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanh_fast(acc[a][b][r] + bias);
         }
       } else if (EPI == EPI_DPRELU) {
         const float* __restrict__ auxp = p.aux;
-        float pre[16];
+        float pre[NR];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pre[r] = auxp[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * p.ldaux + col];
+        for (int r = 0; r < NR; ++r) pre[r] = auxp[(size_t)(rbase + rowoff(r)) * p.ldaux + col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
           const float v = acc[a][b][r];
           const bool pos = pre[r] > 0.f;
           Cp[(size_t)row * p.ldc + col] = pos ? v : slopeE * v;
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       } else if (EPI == EPI_SLAB) {
         float* __restrict__ Sp = p.C + (size_t)split * p.slab_stride;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
           Sp[(size_t)row * p.ldc + col] = acc[a][b][r];
         }
       }

@@ -124,9 +124,13 @@ typedef TileCfg<64, 64, 2, 2, 4, 16> Cfg0;     //  64x 64x16  (default)
 typedef TileCfg<64, 64, 2, 2, 4, 32> Cfg1;     //  64x 64x32
 typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
 typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
-constexpr int N_TILE_CFGS = 4;
-const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128};
-const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128};
+typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32: launches too small to fill the chip
+constexpr int N_TILE_CFGS = 5;
+const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
+const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
+// Below ~96 blocks of 64x64 (measured crossover: 1024 rows x 352) a block has its CU to itself and the launch time is one block's chain of
+// dependent MFMAs; 32x32 tiles on the 16-wide MFMA quarter that chain and quadruple the blocks.
+constexpr int SMALL_LAUNCH_BLOCKS = 96;
 int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
 int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
 
@@ -134,8 +138,14 @@ int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
   return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
 }
 
+int choose_cfg(int M, int N, int K) {
+  int cfg = pick_cfg(M, N, K);
+  if (cfg == 0 && g_force_cfg < 0 && ((M + 63) / 64) * ((N + 63) / 64) <= SMALL_LAUNCH_BLOCKS) cfg = 4;
+  return cfg;
+}
+
 int gemm_blocks(int M, int N, int K) {
-  const int c = pick_cfg(M, N, K);
+  const int c = choose_cfg(M, N, K);
   return ((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
 }
 
@@ -174,11 +184,12 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
 template <int LA, int LB, int XA, int XB, int EPI>
 hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0},
                        int cfg = -1) {
-  if (cfg < 0) cfg = pick_cfg(M, N, a.kchunk);
+  if (cfg < 0) cfg = (splits > 1) ? pick_cfg(M, N, a.kchunk) : choose_cfg(M, N, a.kchunk);
   switch (cfg) {
     case 1: return launch_gemm_cfg<Cfg1, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     case 2: return launch_gemm_cfg<Cfg2, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     case 3: return launch_gemm_cfg<Cfg3, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
+    case 4: return launch_gemm_cfg<Cfg4, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     default: return launch_gemm_cfg<Cfg0, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
   }
 }
@@ -602,7 +613,7 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   pick_splits(MP, e->WP, e->WP, SH, kcH);
   pick_splits(MP, e->LP, e->WP, SO, kcO);
   // every dgrad writes [MP,WP]: one tile shape for all of them, so the slope partial counts agree
-  const int cfg_d = pick_cfg(MP, e->WP, e->WP);
+  const int cfg_d = choose_cfg(MP, e->WP, e->WP);
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   // output layer
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W,

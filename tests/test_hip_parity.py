@@ -61,13 +61,16 @@ def per_tensor(flat, dims):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 32, 32), (256, 352, 448), (384, 96, 64), (128, 160, 832)])
-def test_mfma_gemm_variants(engine_cls, variant, shape):
-    """The engine's MFMA kernel in its three operand layouts against an fp64 matmul."""
+def test_mfma_gemm_variants(engine_cls, variant, shape, tile):
+    """The engine's MFMA kernel, every tile configuration (64x64x16, 64x64x32, 64x128x16, 128x128x16 on the 32-wide
+    MFMA; 32x32x32 on the 16-wide one), in its three operand layouts, against an fp64 matmul."""
     from sdrm_amd import _lib
     import ctypes as C
     lib = _lib.load()
+    lib.sdrm_debug_set_tile(tile)
     M, N, K = shape
     if variant == 2:
         M, K = (K // 32) * 32, ((M + 127) // 128) * 128
@@ -86,6 +89,7 @@ def test_mfma_gemm_variants(engine_cls, variant, shape):
     dC = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     rc = lib.sdrm_debug_gemm(variant, C.c_void_p(dA.data_ptr()), C.c_void_p(dB.data_ptr()), C.c_void_p(dC.data_ptr()),
                              M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    lib.sdrm_debug_set_tile(-1)
     assert rc == 0
     torch.cuda.synchronize()
     got = dC.cpu().numpy()
