@@ -17,7 +17,12 @@ SHAPES = [  # (variant, M, N, K, label)    variant 0: A[M,K]*B[N,K]^T   1: A[M,K
     (1, 24576, 352, 352, "train dgrad   B=8192"),
     (2, 352, 352, 24576, "train wgrad   B=8192 (no split)"),
     (0, 5504, 352, 352, "sample fwd    n=5429"),
-    (0, 1024, 352, 352, "1024 rows/GPU (8-GPU shard)"),
+    (0, 3072, 352, 352, "3072 rows (8-GPU train shard)"),
+    (1, 3072, 352, 352, "3072 rows dgrad"),
+    (0, 6144, 352, 352, "6144 rows (4-GPU train shard)"),
+    (0, 1408, 352, 352, "1358 rows (4-GPU sample shard)"),
+    (0, 2752, 352, 352, "2715 rows (2-GPU sample shard)"),
+    (0, 1024, 352, 352, "1024 rows"),
     (0, 512, 352, 352, "train fwd     B=160"),
     (0, 1664, 832, 928, "ml100k fwd L0 B=550"),
     (0, 1664, 832, 832, "ml100k fwd    B=550"),
