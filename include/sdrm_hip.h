@@ -81,7 +81,8 @@ int sdrm_get_schedule(const sdrm_engine* e, float* beta_host, float* alpha_host,
 /* ---- parameters / optimiser state (nn.Module.state_dict / torch.optim.Adam state) ------------ */
 int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream);
 int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream);
-/* Gradient of the last backward, flat [P] (what autograd leaves in p.grad after :336). */
+/* Gradient of the last backward, flat [P] (what autograd leaves in p.grad after :336).  If that backward was
+ * given a caller buffer (`grad`), this reads from it: the buffer must still be alive. */
 int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream);
 /* Adam first/second moments, flat [P] each, and the global step counter (Q8). */
 int sdrm_get_adam_state(const sdrm_engine* e, float* exp_avg, float* exp_avg_sq, int64_t* step_host, void* stream);

@@ -39,7 +39,20 @@ __device__ __forceinline__ float dot_strided(const float* __restrict__ x, long s
       s2 = fmaf(xv[u + 2], yv[u + 2], s2); s3 = fmaf(xv[u + 3], yv[u + 3], s3);
     }
   }
-  for (; t < n; ++t) s0 = fmaf(x[t * sx], y[t * sy], s0);
+  if (t < n) {   // remainder as one more predicated batch (a scalar tail loop would be n%16 dependent round trips)
+    float xv[16], yv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool in = t + u < n;
+      xv[u] = in ? x[(t + u) * sx] : 0.f;
+      yv[u] = in ? y[(t + u) * sy] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      s0 = fmaf(xv[u], yv[u], s0); s1 = fmaf(xv[u + 1], yv[u + 1], s1);
+      s2 = fmaf(xv[u + 2], yv[u + 2], s2); s3 = fmaf(xv[u + 3], yv[u + 3], s3);
+    }
+  }
   return (s0 + s1) + (s2 + s3);
 }
 
@@ -397,7 +410,13 @@ __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
   } else if (i < n1 + n2 + n3) {
     const int j = i - n1 - n2;
     float s = 0.f;
-    for (int t = 0; t < nt; ++t) s += a.dE[(size_t)t * a.T + j];
+    for (int t0 = 0; t0 < nt; t0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (t0 + u < nt) ? a.dE[(size_t)(t0 + u) * a.T + j] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     a.g[a.off_be + j] = s;
   }
 }

@@ -49,6 +49,7 @@ struct sdrm_engine {
   int *tdev = nullptr;
   int64_t *Tj_dev = nullptr;
   int *rowid_dev = nullptr;
+  const float* grad_src = nullptr;   // where the last backward wrote the flat gradient (internal g or the caller's buffer)
   float *rev_dev = nullptr;          // [3][T+1] reverse-step coefficients c1, sqrt(alpha), sqrt(beta)
   std::vector<int> smp_nact, smp_perm;
   std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
@@ -248,7 +249,8 @@ void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
   S = (Mrows + kchunk - 1) / kchunk;
 }
 
-void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks) {
+void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks, float* gdst = nullptr) {
+  float* gbase = gdst ? gdst : e->g;
   const int L = e->L, W = e->W, T = e->T, H = e->H;
   int n = 0;
   auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, const float* src, int src_ld,
@@ -257,7 +259,7 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
     j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
     j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
     j.inner = inner;
-    j.gdst = e->g + off; j.g_ld = flat_ld;
+    j.gdst = gbase + off; j.g_ld = flat_ld;
   };
   // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
   add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
@@ -513,7 +515,7 @@ int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream) {
 int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream) {
   if (!e || !flat) return SDRM_ERR_ARG;
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
-  HIP_TRY(me, hipMemcpyAsync(flat, e->g, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(me, hipMemcpyAsync(flat, e->grad_src ? e->grad_src : e->g, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SDRM_OK;
 }
 
@@ -636,13 +638,16 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
   HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
                                   Prof{e, PC_WGRAD_L0, fl0})));
+  // the flat gradient is written where the caller wants it (a DDP bucket) - no copy afterwards
+  float* gout = grad ? grad : e->g;
+  e->grad_src = gout;
   JobTable tab;
-  build_jobs(e, tab, S0, SH, SO, dgrad_blocks);
+  build_jobs(e, tab, S0, SH, SO, dgrad_blocks, gout);
   hipLaunchKernelGGL(k_grad_finalize, dim3(512, tab.n), dim3(256), 0, st, tab);
   HIP_TRY(e, hipGetLastError());
   EmbBwdArgs ea{};
   ea.dC0T = e->dC0; ea.TP = e->TP;
-  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = e->g;
+  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = gout;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
   hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 1023) / 1024), dim3(1024), 0, st, ea);
@@ -652,7 +657,6 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
     hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
     HIP_TRY(e, hipGetLastError());
   }
-  if (grad && grad != e->g) HIP_TRY(e, hipMemcpyAsync(grad, e->g, e->P * 4, hipMemcpyDeviceToDevice, st));
   e->last_S = S0; e->last_dgrad_blocks = dgrad_blocks;
   return SDRM_OK;
 }
