@@ -60,6 +60,9 @@ struct sdrm_engine {
   const float* cur_x0 = nullptr;
   bool fwd_done = false;
   int last_S = 1, last_dgrad_blocks = 0;
+  bool bwd_upper_done = false;
+  float* bwd_dcur = nullptr;
+  int bwd_S0 = 1, bwd_kc0 = 0, bwd_SH = 1, bwd_SO = 1, bwd_dgrad_blocks = 0;
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
@@ -597,11 +600,15 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   return SDRM_OK;
 }
 
-int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+// Backward in two halves so that a data-parallel caller can all-reduce the UPPER gradient bucket
+// (flat[off_a0 ..): slopes, hidden and output layer - final once the last dgrad is done) while the lower half
+// (layer-0 wgrad, its slab reduction, the embedding backward -> flat[0 .. off_a0)) is still running.
+int sdrm_train_backward_upper(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
   if (!e) return SDRM_ERR_ARG;
   if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
   hipStream_t st = (hipStream_t)stream;
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
+  e->bwd_upper_done = false;
   SeedArgs sa{};
   sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
@@ -618,8 +625,7 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   const int cfg_d = choose_cfg(MP, e->WP, e->WP);
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   // output layer
-  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W,
-               fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
+  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, kcO,
                                    e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
   float* dcur = e->dA;
@@ -635,15 +641,39 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
                           slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
     float* tmp = dcur; dcur = dnext; dnext = tmp;
   }
-  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
-  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
-                                  Prof{e, PC_WGRAD_L0, fl0})));
   // the flat gradient is written where the caller wants it (a DDP bucket) - no copy afterwards
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
   JobTable tab;
   build_jobs(e, tab, S0, SH, SO, dgrad_blocks, gout);
-  hipLaunchKernelGGL(k_grad_finalize, dim3(512, tab.n), dim3(256), 0, st, tab);
+  // upper bucket = every job at or above the layer-0 slope in the flat order
+  JobTable up{};
+  for (int j = 0; j < tab.n; ++j)
+    if (tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P) up.j[up.n++] = tab.j[j];
+  hipLaunchKernelGGL(k_grad_finalize, dim3(512, up.n), dim3(256), 0, st, up);
+  HIP_TRY(e, hipGetLastError());
+  e->bwd_dcur = dcur; e->bwd_S0 = S0; e->bwd_kc0 = kc0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
+  e->bwd_upper_done = true;
+  return SDRM_OK;
+}
+
+int sdrm_train_backward_lower(sdrm_engine* e, float* grad, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done || !e->bwd_upper_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward_lower: upper half not run");
+  hipStream_t st = (hipStream_t)stream;
+  const int B = e->cur_B, MP = e->cur_MP;
+  float* gout = grad ? grad : e->g;
+  if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_lower: different gradient buffer than the upper half");
+  const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
+  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
+  HIP_TRY(e, (gemm_wgrad<XF_NONE>(e->bwd_dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, e->bwd_S0, e->bwd_kc0, e->slab0,
+                                  e->db0s, st, Prof{e, PC_WGRAD_L0, fl0})));
+  JobTable tab;
+  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
+  JobTable lo{};
+  for (int j = 0; j < tab.n; ++j)
+    if (!(tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P)) lo.j[lo.n++] = tab.j[j];
+  hipLaunchKernelGGL(k_grad_finalize, dim3(512, lo.n), dim3(256), 0, st, lo);
   HIP_TRY(e, hipGetLastError());
   EmbBwdArgs ea{};
   ea.dC0T = e->dC0; ea.TP = e->TP;
@@ -657,7 +687,20 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
     hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
     HIP_TRY(e, hipGetLastError());
   }
-  e->last_S = S0; e->last_dgrad_blocks = dgrad_blocks;
+  e->bwd_upper_done = false;
+  return SDRM_OK;
+}
+
+int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+  int rc = sdrm_train_backward_upper(e, sums, grad, loss, stream);
+  if (rc) return rc;
+  return sdrm_train_backward_lower(e, grad, stream);
+}
+
+int sdrm_grad_buckets(const sdrm_engine* e, int64_t* lower_len, int64_t* upper_len) {
+  if (!e || !lower_len || !upper_len) return SDRM_ERR_ARG;
+  *lower_len = e->off_a0;
+  *upper_len = e->P - e->off_a0;
   return SDRM_OK;
 }
 

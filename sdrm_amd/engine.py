@@ -151,6 +151,22 @@ class Engine:
                     "sdrm_train_backward")
         return self._loss
 
+    def train_backward_upper(self, sums=None, grad=None):
+        """First half of phase 2: finalises grad[lower_len:] (see `grad_buckets`)."""
+        sums = self._sums if sums is None else sums
+        self._check(self.lib.sdrm_train_backward_upper(self._h, _ptr(sums), _ptr(grad), _ptr(self._loss), _stream()),
+                    "sdrm_train_backward_upper")
+        return self._loss
+
+    def train_backward_lower(self, grad=None):
+        """Second half of phase 2: layer-0 weight gradient + embedding backward -> grad[:lower_len]."""
+        self._check(self.lib.sdrm_train_backward_lower(self._h, _ptr(grad), _stream()), "sdrm_train_backward_lower")
+
+    def grad_buckets(self):
+        lo, up = C.c_int64(), C.c_int64()
+        self._check(self.lib.sdrm_grad_buckets(self._h, C.byref(lo), C.byref(up)), "sdrm_grad_buckets")
+        return int(lo.value), int(up.value)
+
     def adam_step(self, lr, grad=None):
         """Phase 3: coupled-L2 Adam (:309,:337) at the caller's per-epoch lr (:316)."""
         self._check(self.lib.sdrm_adam_step(self._h, _ptr(grad), float(lr), _stream()), "sdrm_adam_step")

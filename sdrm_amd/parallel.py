@@ -8,8 +8,10 @@ step, nothing else:
   1. all-reduce(sum) of 5 float64 loss scalars {sum D^2, sum (R-S)^2, sum R, sum R^2, count} after the
      three forwards: var(R) and both mse means of `score_matching_loss` (train_SDRM.py:196-198) are
      over the GLOBAL batch, and the gradient flows through them (Q6).
-  2. all-reduce(sum) of the flat gradient [P] fp32; every rank then applies the identical Adam update
-     (train_SDRM.py:337), so parameters stay replicated without a broadcast.
+  2. all-reduce(sum) of the flat gradient [P] fp32, in two buckets: the upper one (slopes, hidden and output
+     layer) is exchanged while the layer-0 / embedding backward is still running, the lower one right after;
+     every rank then applies the identical Adam update (train_SDRM.py:337), so parameters stay replicated
+     without a broadcast.
 
 Randomness is Philox keyed by the GLOBAL row index, so G ranks draw exactly what one rank draws.
 Sampling shards users with no communication at all.
@@ -30,8 +32,8 @@ def shard_rows(n_rows: int, rank: int, world: int):
 
 
 class ShardedTrainer:
-    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None):
-        self.engine, self.rank, self.world, self.group = engine, rank, world, group
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None, overlap=True):
+        self.engine, self.rank, self.world, self.group, self.overlap = engine, rank, world, group, overlap
         dev = device if device is not None else getattr(engine, "device", "cpu")
         P = n_params if n_params is not None else engine.P
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -52,7 +54,17 @@ class ShardedTrainer:
             noise, t, keep = explicit
             e.train_forward(x0_local, noise=noise, t=t, keep=keep, nd=nd, row0=row0, sums=self.sums)
         dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
-        loss = e.train_backward(sums=self.sums, grad=self.grad)
-        dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+        if self.overlap and hasattr(e, "train_backward_upper"):
+            # bucketed exchange: the upper bucket (slopes, hidden and output layer; final after the last dgrad)
+            # is all-reduced on the collective's own stream while the layer-0 / embedding backward still runs
+            lower = e.grad_buckets()[0]
+            loss = e.train_backward_upper(sums=self.sums, grad=self.grad)
+            work = dist.all_reduce(self.grad[lower:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            e.train_backward_lower(grad=self.grad)
+            dist.all_reduce(self.grad[:lower], op=dist.ReduceOp.SUM, group=self.group)
+            work.wait()
+        else:
+            loss = e.train_backward(sums=self.sums, grad=self.grad)
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
         e.adam_step(lr, grad=self.grad)
         return loss

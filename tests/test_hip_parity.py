@@ -376,9 +376,17 @@ def test_sharded_equals_single(engine_cls):
         e.train_forward(x0[r0:r0 + rows], seed=seed, step=step, row0=r0, sums=s)
         engs.append(e); sums.append(s)
     total = sums[0] + sums[1]
-    for e in engs:
-        g = torch.zeros(e.P, dtype=torch.float32, device="cuda")
-        e.train_backward(sums=total, grad=g)
+    lower, upper = engs[0].grad_buckets()
+    assert lower + upper == engs[0].P
+    for k, e in enumerate(engs):
+        g = torch.full((e.P,), float("nan"), dtype=torch.float32, device="cuda")
+        if k == 0:                                   # the bucketed form must fill exactly its two halves
+            e.train_backward_upper(sums=total, grad=g)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(g[:lower]).all()) and bool(torch.isfinite(g[lower:]).all())
+            e.train_backward_lower(grad=g)
+        else:
+            e.train_backward(sums=total, grad=g)
         grads.append(g)
     gsum = grads[0] + grads[1]
     assert rel_l2(gsum.cpu().numpy(), ref.get_grads().cpu().numpy()) <= 2e-5

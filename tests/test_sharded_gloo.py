@@ -65,6 +65,23 @@ class OraclePhases:
         grad.copy_(torch.cat([grads[n].reshape(-1) for n in self.names]))
         return torch.tensor(0.5 * (A + C) / den)
 
+    # the two-bucket form of phase 2 (sdrm_train_backward_upper / _lower)
+    def grad_buckets(self):
+        shapes = synth.param_shapes(L, W, T, H)
+        lower = sum(int(np.prod(shapes[n])) for n in ("emb_layer.weight", "emb_layer.bias", "dnn.0.weight", "dnn.0.bias"))
+        return lower, self.P - lower
+
+    def train_backward_upper(self, sums=None, grad=None):
+        full = torch.zeros(self.P)
+        loss = self.train_backward(sums=sums, grad=full)
+        lower = self.grad_buckets()[0]
+        grad[lower:] = full[lower:]
+        self._lower = full[:lower].clone()
+        return loss
+
+    def train_backward_lower(self, grad=None):
+        grad[:self._lower.numel()] = self._lower
+
     def adam_step(self, lr, grad=None):
         shapes = synth.param_shapes(L, W, T, H)
         out, off = {}, 0
@@ -82,12 +99,12 @@ class OraclePhases:
         return loss
 
 
-def _worker(rank, world, port, init, x0, q):
+def _worker(rank, world, port, init, x0, q, overlap=True):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     eng = OraclePhases(init)
-    tr = ShardedTrainer(eng, rank, world, device="cpu", n_params=eng.P)
+    tr = ShardedTrainer(eng, rank, world, device="cpu", n_params=eng.P, overlap=overlap)
     r0, rows = shard_rows(B, rank, world)
     losses = []
     for step in range(3):
@@ -105,7 +122,8 @@ def _free_port():
 
 
 @pytest.mark.timeout(180)
-def test_two_rank_gloo_matches_single_process():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_gloo_matches_single_process(overlap):
     init = synth.init_params(L, W, T, H, seed=13)
     x0 = synth.synth_latents(B, L, seed=14)
     single = OraclePhases(init)
@@ -115,7 +133,7 @@ def test_two_rank_gloo_matches_single_process():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, init, x0, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, init, x0, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=150) for _ in procs]
