@@ -194,6 +194,11 @@ def pmc_traffic(kernel_class: str):
     data = json.load(open(files[-1]))
     for name, v in data.get("kernels", {}).items():
         if needle in name:
+            # the same template serves train launches (24576 rows: the largest grid) and sampling launches
+            rows = sorted(v.get("by_grid", []), key=lambda r: r["grid_size"])
+            if rows:
+                pick = rows[0] if kernel_class.startswith("sample") else rows[-1]
+                return pick["hbm_bytes_per_launch"], os.path.basename(files[-1])
             return v["hbm_bytes_per_launch_mean"], os.path.basename(files[-1])
     return None, None
 

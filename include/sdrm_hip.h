@@ -186,6 +186,10 @@ const char* sdrm_build_info(void);
 /* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);
+/* Row chains of a sampling call (csrc/sdrm_hip.hip: independent row ranges run on separate HIP streams so that one
+ * chain's launch gaps are filled by another's kernels): -1 = by size (default), 1..4 forced; also env SDRM_CHAINS.
+ * Results do not depend on it (rows are independent and randoms are keyed by row).  Test / tuning aid. */
+int sdrm_debug_set_chains(int chains);
 /* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, 4 = 32x32x32 on the 16x16x4 MFMA,
  * -1 = automatic: 64x64x16, or 32x32x32 when the launch has too few rows to fill the chip);
  * also env SDRM_TILE.  Tuning aid. */

@@ -432,6 +432,7 @@ struct Job {
   int inner;          // >1: scalar job, sum src[k*slab_stride + q] over k<nslabs, q<inner (slope partials)
   float* gdst; int g_ld;   // where k_grad_finalize writes: flat gradient (g + flat_off, flat_ld) or a scratch table
   float* dst; int dst_ld;                                          // compute copy (may be null)
+  float* dstT; int dstT_ld;                                        // transposed compute copy [col][row] (may be null)
 };
 constexpr int MAX_JOBS = 12;
 struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
@@ -512,6 +513,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
       a.p[fi] = w;
     }
     if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+    if (jb.dstT != nullptr && c < jb.ncols) jb.dstT[(size_t)c * jb.dstT_ld + r] = w;
   }
 }
 
@@ -573,12 +575,12 @@ __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
 // pair's keep bits for step i-1.
 struct ReverseArgs {
   float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj; const int* rowid;
-  int n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
+  int s0, n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
   int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
 };
 
 __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
-  const int s = blockIdx.y;                      // slot; rows [0, n) of this launch are the active prefix
+  const int s = a.s0 + blockIdx.y;               // slot; this launch covers the active slots [s0, n) of one row chain
   const int q = blockIdx.x * 256 + threadIdx.x;
   const int c = 2 * q;
   if (c >= a.L || s >= a.n) return;

@@ -1,26 +1,36 @@
 // fp32 MFMA GEMM for the SDRM eps-net on gfx950 (CDNA4).
 //
-// One kernel template covers the three contractions of a Linear layer
-// (forward x*W^T, dgrad dY*W, wgrad dY^T*X) by choosing how each operand tile is
-// brought into LDS.  Inside LDS both operands are always k-major
-// (As[k][i], Bs[k][j]), which is the layout v_mfma_f32_32x32x2_f32 consumes with
-// conflict-free ds_read_b32: lane l reads As[k0 + (l>>5)][i0 + (l&31)].
+// One kernel template covers the contractions of a Linear layer (forward x*W^T, dgrad dY*(W^T)^T against the
+// transposed weight copy, wgrad dY^T*X) by choosing how each operand tile is brought into LDS:
 //
-//   block tile BM x BN (template), K-step 16, 256 threads = 4 waves as WM x WN,
-//   each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each),
-//   LDS double-buffered, one barrier per K-step, global->register prefetch of the next K-step
-//   issued before the MFMAs of the current one, all fragments of a K-step read into registers
-//   ahead of its MFMAs (the compiler places counted lgkmcnt waits).
+//   NT GEMMs (both operands k-contiguous in memory: every forward and every dgrad) keep the tiles k-MINOR in
+//   LDS - As[i][k], row stride BK+4 floats: the float4 a thread loaded is stored as it is (ds_write_b128) and a
+//   lane fetches its fragments of a whole K-step with BK/8 ds_read_b128 per MFMA tile edge.  The MFMA
+//   contraction does not care which k a (group, lane-half) slot carries as long as A and B agree.
+//   wgrad (both operands row-major over the reduction index) and the 16-wide-MFMA tiles keep them k-MAJOR,
+//   As[k][i], read with conflict-free ds_read_b32: lane l reads As[k0 + (l>>5)][i0 + (l&31)].
 //
-// MFMAs are issued unconditionally: operand rows/cols beyond the matrix are zero-filled in LDS, and
-// a work-group is as slow as its busiest wave anyway, so predicating whole MFMA tiles buys nothing
-// and costs exec-mask branches around every MFMA.
+//   block tile BM x BN (template), K-step BK, 256 threads = 4 waves as WM x WN, each wave TM x TN MFMA tiles of
+//   32x32 (v_mfma_f32_32x32x2_f32, 16 accumulator VGPRs) or 16x16 (v_mfma_f32_16x16x4_f32, 4 VGPRs).
+//
+// Main loop (both layouts): two LDS stages, ONE barrier per K-step, fragments double-buffered in registers.
+// A wave issues in order and its MFMAs are one dependent chain per accumulator tile, so everything else of
+// the pipeline is cut into small pieces that ride in the 64-cycle shadow behind each MFMA issue (order pinned
+// with sched_barrier): fragment reads of step i+1, LDS stores of step i+2 out of the prefetch registers, global
+// loads of step i+4.  Measured on a lone work-group (tools/gemm_stamps.py): 715 -> 597 cycles per 8 MFMAs
+// (512 is the matrix pipe itself); full launches 24576x352x352: 58.7 -> 55.2 us (110 TFLOP/s padded).
+//
+// MFMAs are issued unconditionally inside an active wave: operand rows/cols beyond the matrix are zero-filled
+// in LDS.  A wave whose whole tile range lies outside the matrix skips reads and MFMAs (it only feeds the
+// pipeline), which returns its SIMD's matrix pipe to the other work-groups on the CU.
 //
 // fp32-input MFMA is bit-for-bit a k-ordered fmaf chain, so results sit well inside the 1e-4
 // normwise parity bar.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "philox.h"
 
@@ -40,6 +50,15 @@ enum : int {
 
 constexpr int NTHREADS = 256;
 
+// diagnostic builds only (tools/gemm_stamps.py -DSDRM_DIAG=mask): drop a piece of the NT main loop to see what
+// it costs a work-group - bit0 loop loads, bit1 LDS stores, bit2 barriers
+#ifndef SDRM_DIAG
+#define SDRM_DIAG 0
+#endif
+#define DIAG_LD(x) do { if (!(SDRM_DIAG & 1)) { x; } } while (0)
+#define DIAG_ST(x) do { if (!(SDRM_DIAG & 2)) { x; } } while (0)
+#define DIAG_BAR() do { if (!(SDRM_DIAG & 4)) __syncthreads(); } while (0)
+
 // MF = edge of the MFMA output tile: 32 -> v_mfma_f32_32x32x2_f32 (16 accumulator VGPRs per tile), 16 ->
 // v_mfma_f32_16x16x4_f32 (4 VGPRs).  Same flop rate; the 16-wide form lets a 32x32 block tile be split over four
 // waves, which is what a launch with few rows needs: it cannot fill the chip with 64x64 tiles, and a lone block's
@@ -51,7 +70,9 @@ struct TileCfg {
   static constexpr int TM = BM_ / WM_ / MF_, TN = BN_ / WN_ / MF_;   // MFMA tiles per wave
   static constexpr int PADMAX = (MF_ == 32) ? 4 : 16;
   static constexpr int LDA = BM_ + PADMAX, LDB = BN_ + PADMAX;     // upper bound of the LDS row strides (floats)
-  static constexpr int STAGE = BK * (LDA + LDB);                   // floats per pipeline stage
+  static constexpr int LDK = BK_ + 4;                              // row stride of the k-minor layout (NT GEMMs)
+  static constexpr int STAGE_KMAJOR = BK * (LDA + LDB), STAGE_KMINOR = (BM_ + BN_) * LDK;
+  static constexpr int STAGE = STAGE_KMAJOR > STAGE_KMINOR ? STAGE_KMAJOR : STAGE_KMINOR;   // floats per pipeline stage
   static_assert(WM_ * WN_ == 4, "4 waves per work-group");
   static_assert(MF_ == 32 || MF_ == 16, "MFMA tile edge");
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one MFMA tile");
@@ -141,6 +162,26 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4
   }
 }
 
+// k-minor variant (both operands k-contiguous in global memory, i.e. the NT GEMMs): the float4 a thread
+// loaded goes to LDS as one ds_write_b128 at [row][4*kq], row stride BK+4 floats (conflict-free for the
+// 16-lane groups of a b128 access: 16 B x odd multiple).
+template <int XF, int ROWS, int LDK, int BK>
+__device__ __forceinline__ void store_tile_km(float* __restrict__ dst, const float4 (&r)[ROWS * BK / 4 / NTHREADS],
+                                              float slope, int tid) {
+  constexpr int NV = ROWS * BK / 4 / NTHREADS;
+  constexpr int KQ = BK / 4;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const int f = tid + s * NTHREADS;
+    float4 v = r[s];
+    if (XF == XF_PRELU) {
+      v.x = prelu_f(v.x, slope); v.y = prelu_f(v.y, slope); v.z = prelu_f(v.z, slope); v.w = prelu_f(v.w, slope);
+    }
+    const int i = f / KQ, kq = f % KQ;
+    *reinterpret_cast<float4*>(dst + i * LDK + 4 * kq) = v;
+  }
+}
+
 // XCD-aware remap (cdna guide T1, bijective form): hardware deals consecutive block ids round-robin
 // over the 8 XCDs; give every XCD a contiguous range of logical tiles so that the N-tiles of one
 // M-tile (which re-read the same activation rows) share an L2.
@@ -161,9 +202,21 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   // when LD = 16 (mod 32).
   constexpr int LDA = BM + (MF == 16 ? 16 : (LOADA == LD_KCONTIG ? 2 : 4));
   constexpr int LDB = BN + (MF == 16 ? 16 : (LOADB == LD_KCONTIG ? 2 : 4));
+  // NT GEMMs (both operands k-contiguous: every forward, and dgrad against the transposed weight copy) keep
+  // the operands k-MINOR in LDS: stores are the loaded float4 as they are, and a lane fetches its whole K-step
+  // of fragments with BK/8 ds_read_b128 per MFMA tile edge instead of BK/2 ds_read_b32.  The MFMA contraction
+  // does not care which k a (group, lane-half) slot carries as long as A and B agree: lane-half h takes
+  // k = h*BK/2 .. h*BK/2 + BK/2-1 of the K-step.
+  constexpr bool KM = (LOADA == LD_KCONTIG && LOADB == LD_KCONTIG && MF == 32);
+  constexpr int LDK = Cfg::LDK;
+  constexpr int BOFF = KM ? BM * LDK : BK * LDA;   // B operand's offset inside a stage
+  constexpr int NQ = BK / 8;                       // float4 fragments per lane per MFMA tile edge per K-step
   constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
   static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
+#ifdef SDRM_STAMPS
+  unsigned long long t_in = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,83 +270,196 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
   };
   auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
     float* An = smem + stage * Cfg::STAGE;
-    store_tile<LOADA, XFA, BM, LDA, BK>(An, xa, slopeA, tid);
-    store_tile<LOADB, XFB, BN, LDB, BK>(An + BK * LDA, xb, slopeB, tid);
+    if constexpr (KM) {
+      store_tile_km<XFA, BM, LDK, BK>(An, xa, slopeA, tid);
+      store_tile_km<XFB, BN, LDK, BK>(An + BOFF, xb, slopeB, tid);
+    } else {
+      store_tile<LOADA, XFA, BM, LDA, BK>(An, xa, slopeA, tid);
+      store_tile<LOADB, XFB, BN, LDB, BK>(An + BOFF, xb, slopeB, tid);
+    }
   };
   // A wave whose whole 32-granular tile range lies outside the matrix (the half-empty last tile row /
   // column: 352 = 5.5 x 64) issues no LDS reads and no MFMAs; it still loads, stores and meets the
   // barriers.  Its SIMD's matrix pipe goes to the other work-groups resident on the CU.
   const bool wave_active = (m0 + wm * (BM / Cfg::WM) < p.limA) && (n0 + wn * (BN / Cfg::WN) < p.limB);
-  // compute() is split in two so that a K-step can issue its first fragment reads right after the
-  // barrier, ahead of the LDS stores of the next step's operands (they queue in order on the LDS
-  // pipe): the first MFMA then waits ~one LDS latency instead of stores + latency.
-  float af[2][TM], bf[2][TN];
-  auto first_frags = [&](int stage) {
-    const float* As = smem + stage * Cfg::STAGE;
-    const float* Bs = As + BK * LDA;
-    if (wave_active) {
+  const int aoffk = (wm * (BM / Cfg::WM) + l31) * LDK + (BK / 2) * lhi;
+  const int boffk = (wn * (BN / Cfg::WN) + l31) * LDK + (BK / 2) * lhi;
+
+  if constexpr (KM) {
+    // NT main loop.  A wave issues in order and its MFMAs form one dependent chain per accumulator tile, so the
+    // only slots in which its other instructions cost nothing are the 64-cycle shadows right after each MFMA
+    // issue (measured on a lone work-group: every LDS read / LDS store / global load / barrier placed outside
+    // those shadows adds its full issue time to the K-step: 715 cycles per 8 MFMAs instead of 512+).  Hence one
+    // small piece of the pipeline goes behind each MFMA group, order pinned with sched_barrier:
+    //   fragments of K-step i+1 are read (b128) into the other register set,
+    //   the operands of step i+2 go from their prefetch registers into the LDS stage step i vacated,
+    //   the global loads of step i+4 are issued.
+    // Two LDS stages, one barrier per K-step.
+    constexpr int NS = 4 * NQ;   // MFMA groups (slots) per K-step
+    static_assert(NS >= 2 * NQ + 4, "not enough MFMA shadows for the pipeline pieces");
+    float4 fa0[TM][NQ], fb0[TN][NQ], fa1[TM][NQ], fb1[TN][NQ];
+    auto rd_all = [&](float4 (&fa)[TM][NQ], float4 (&fb)[TN][NQ], int stage) {
+      const float* As = smem + stage * Cfg::STAGE;
+      const float* Bs = As + BOFF;
 #pragma unroll
-      for (int a = 0; a < TM; ++a) af[0][a] = As[aoff + MF * a];
+      for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bf[0][b] = Bs[boff + MF * b];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto compute = [&](int stage) {
-    const float* As = smem + stage * Cfg::STAGE;
-    const float* Bs = As + BK * LDA;
-    if (wave_active) {
-      // Fragment reads run one MFMA group ahead of their use (two register sets); sched_barrier pins the
-      // issue order so the LDS latency of group s+1 hides under the MFMAs of group s.
+        for (int a = 0; a < TM; ++a) fa[a][q] = *reinterpret_cast<const float4*>(As + aoffk + MF * a * LDK + 4 * q);
 #pragma unroll
-      for (int s = 0; s < BK / KG; ++s) {
-        const int cur = s & 1, nxt = cur ^ 1;
-        if (s + 1 < BK / KG) {
+        for (int b = 0; b < TN; ++b) fb[b][q] = *reinterpret_cast<const float4*>(Bs + boffk + MF * b * LDK + 4 * q);
+      }
+    };
+    // one K-step: MFMAs out of (ca, cb); pieces: read (na, nb) from stage rs, store (xa, xb) into stage ss, load step li
+    auto kstep = [&](auto active_tag, const float4 (&ca)[TM][NQ], const float4 (&cb)[TN][NQ], float4 (&na)[TM][NQ],
+                     float4 (&nb)[TN][NQ], int rs, float4 (&xa)[NVA], float4 (&xb)[NVB], int ss, int li) {
+      constexpr bool ACTIVE = decltype(active_tag)::value;
+      const float* Ar = smem + rs * Cfg::STAGE;
+      const float* Br = Ar + BOFF;
+      float* Aw = smem + ss * Cfg::STAGE;
+      const int k0 = kb + min(li, nt - 1) * BK;
 #pragma unroll
-          for (int a = 0; a < TM; ++a) af[nxt][a] = As[aoff + KG * (s + 1) * LDA + MF * a];
+      for (int sl = 0; sl < NS; ++sl) {
+        const int q = sl >> 2, j = sl & 3;
+        if constexpr (ACTIVE) {
 #pragma unroll
-          for (int b = 0; b < TN; ++b) bf[nxt][b] = Bs[boff + KG * (s + 1) * LDB + MF * b];
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+              const float av = j == 0 ? ca[a][q].x : j == 1 ? ca[a][q].y : j == 2 ? ca[a][q].z : ca[a][q].w;
+              const float bv = j == 0 ? cb[b][q].x : j == 1 ? cb[b][q].y : j == 2 ? cb[b][q].z : cb[b][q].w;
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+            }
+        }
+        // the piece that rides in this group's shadow
+        if (sl < 2 * NQ) {
+          if constexpr (ACTIVE) {
+            const int rq = sl >> 1;
+            if ((sl & 1) == 0) {
+#pragma unroll
+              for (int a = 0; a < TM; ++a) na[a][rq] = *reinterpret_cast<const float4*>(Ar + aoffk + MF * a * LDK + 4 * rq);
+            } else {
+#pragma unroll
+              for (int b = 0; b < TN; ++b) nb[b][rq] = *reinterpret_cast<const float4*>(Br + boffk + MF * b * LDK + 4 * rq);
+            }
+          }
+        } else if (sl == 2 * NQ) {
+          DIAG_ST((store_tile_km<XFA, BM, LDK, BK>(Aw, xa, slopeA, tid)));
+        } else if (sl == 2 * NQ + 1) {
+          DIAG_ST((store_tile_km<XFB, BN, LDK, BK>(Aw + BOFF, xb, slopeB, tid)));
+        } else if (sl == 2 * NQ + 2) {
+          DIAG_LD((load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid)));
+        } else if (sl == 2 * NQ + 3) {
+          DIAG_LD((load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid)));
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b) {
-            if constexpr (MF == 32) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
-            else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
       }
+      DIAG_BAR();
+    };
+    if (nt > 0) {
+      ld(ra0, rb0, 0);
+      ld(ra1, rb1, 1);
+      st(ra0, rb0, 0);
+      ld(ra0, rb0, 2);
+      st(ra1, rb1, 1);
+      ld(ra1, rb1, 3);
+      __syncthreads();
+#ifdef SDRM_STAMPS
+      if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
+#endif
+      if (wave_active) rd_all(fa0, fb0, 0);
+      __syncthreads();   // stage 0 is overwritten from the first K-step on: every wave must hold its step-0 fragments
+      // step i multiplies out of fragment set i%2, reads step i+1's fragments from stage (i+1)%2, stores step i+2
+      // (prefetch set i%2) into stage i%2 and requests step i+4 into the same set.  (Four prefetch sets, i.e. loads
+      // requested four steps ahead, were measured: 3 % off a lone work-group's loop, 2 % slower on full launches.)
+      auto run = [&](auto tag) {
+        int i = 0;
+        for (; i + 1 < nt; i += 2) {
+          kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 4);
+          kstep(tag, fa1, fb1, fa0, fb0, 0, ra1, rb1, 1, i + 5);
+        }
+        if (i < nt) kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 4);   // odd count (its pieces are harmless)
+      };
+      if (wave_active) run(std::true_type{});
+      else run(std::false_type{});   // a wave whose tile range lies outside the matrix only feeds the pipeline
     }
-    if (do_dbias) {
+  } else {
+    // k-major operands (wgrad: both operands are row-major over the reduction index; also the 16-wide MFMA
+    // tiles of small launches): the same pipeline, fragments fetched with ds_read_b32 - the pair of reads that
+    // feeds MFMA group g of the NEXT K-step rides in the shadow of group g of this one.
+    constexpr int G = BK / KG;   // MFMA groups per K-step
+    static_assert(G >= 8, "pipeline pieces need 8 MFMA shadows");
+    float ka0[TM][G], kb0[TN][G], ka1[TM][G], kb1[TN][G];
+    auto col_sum = [&](int stage) {   // bias gradient: column sums of the A operand (dY^T) of the K-step in `stage`
+      const float* As = smem + stage * Cfg::STAGE;
 #pragma unroll
       for (int k = 0; k < BK; ++k) dbsum += As[k * LDA + tid];
-    }
-  };
-
-  if (nt > 0) {
-    ld(ra0, rb0, 0);
-    st(ra0, rb0, 0);
-    ld(ra0, rb0, 1);
-    ld(ra1, rb1, 2);
-    __syncthreads();
+    };
+    auto kstep = [&](auto active_tag, const float (&ca)[TM][G], const float (&cb)[TN][G], float (&na)[TM][G],
+                     float (&nb)[TN][G], int rs, float4 (&xa)[NVA], float4 (&xb)[NVB], int ss, int li, bool next_valid) {
+      constexpr bool ACTIVE = decltype(active_tag)::value;
+      const float* Ar = smem + rs * Cfg::STAGE;
+      const float* Br = Ar + BOFF;
+      float* Aw = smem + ss * Cfg::STAGE;
+      const int k0 = kb + min(li, nt - 1) * BK;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if constexpr (ACTIVE) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+              if constexpr (MF == 32) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[a][g], cb[b][g], acc[a][b], 0, 0, 0);
+              else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[a][g], cb[b][g], acc[a][b], 0, 0, 0);
+            }
+#pragma unroll
+          for (int a = 0; a < TM; ++a) na[a][g] = Ar[aoff + KG * g * LDA + MF * a];
+#pragma unroll
+          for (int b = 0; b < TN; ++b) nb[b][g] = Br[boff + KG * g * LDB + MF * b];
+        }
+        if (g == G / 2) store_tile<LOADA, XFA, BM, LDA, BK>(Aw, xa, slopeA, tid);
+        else if (g == G / 2 + 1) store_tile<LOADB, XFB, BN, LDB, BK>(Aw + BOFF, xb, slopeB, tid);
+        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid);
+        else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (do_dbias && next_valid) col_sum(rs);
+      __syncthreads();
+    };
+    if (nt > 0) {
+      ld(ra0, rb0, 0);
+      ld(ra1, rb1, 1);
+      st(ra0, rb0, 0);
+      ld(ra0, rb0, 2);
+      st(ra1, rb1, 1);
+      ld(ra1, rb1, 3);
+      __syncthreads();
 #ifdef SDRM_STAMPS
-    if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
+      if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
 #endif
-    int i = 0;
-    for (; i + 1 < nt; i += 2) {
-      first_frags(0);
-      st(ra0, rb0, 1);          // set 0 holds K-step i+1
-      ld(ra0, rb0, i + 3);
-      compute(0);
-      __syncthreads();
-      first_frags(1);
-      st(ra1, rb1, 0);          // set 1 holds K-step i+2
-      ld(ra1, rb1, i + 4);
-      compute(1);
-      __syncthreads();
+      if (wave_active) {
+        const float* As = smem;
+        const float* Bs = As + BOFF;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) ka0[a][g] = As[aoff + KG * g * LDA + MF * a];
+#pragma unroll
+          for (int b = 0; b < TN; ++b) kb0[b][g] = Bs[boff + KG * g * LDB + MF * b];
+        }
+      }
+      if (do_dbias) col_sum(0);
+      __syncthreads();   // stage 0 is overwritten from the first K-step on
+      auto run = [&](auto tag) {
+        int i = 0;
+        for (; i + 1 < nt; i += 2) {
+          kstep(tag, ka0, kb0, ka1, kb1, 1, ra0, rb0, 0, i + 4, true);
+          kstep(tag, ka1, kb1, ka0, kb0, 0, ra1, rb1, 1, i + 5, i + 2 < nt);
+        }
+        if (i < nt) kstep(tag, ka0, kb0, ka1, kb1, 1, ra0, rb0, 0, i + 4, false);
+      };
+      if (wave_active) run(std::true_type{});
+      else run(std::false_type{});
     }
-    if (i < nt) { first_frags(0); compute(0); }   // odd count: the last K-step already sits in stage 0
   }
 #ifdef SDRM_STAMPS
   if (EPI == EPI_PLAIN) t_loop = __builtin_amdgcn_s_memtime();

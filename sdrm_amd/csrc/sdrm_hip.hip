@@ -38,8 +38,10 @@ struct sdrm_engine {
   float *p = nullptr, *m = nullptr, *v = nullptr, *g = nullptr;
   // padded compute copies
   float *W0c = nullptr, *b0c = nullptr, *Whc = nullptr, *bhc = nullptr, *Woc = nullptr, *boc = nullptr;
+  float *WhcT = nullptr, *WocT = nullptr;   // transposed copies [in][out]: dgrad is then an NT GEMM like the forwards
   float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
+  float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
   float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *dB = nullptr, *X = nullptr;
   float *slab0 = nullptr, *slabH = nullptr, *slabO = nullptr, *db0s = nullptr, *dbHs = nullptr, *dbOs = nullptr;
   float *alpha_part = nullptr;
@@ -68,6 +70,12 @@ struct sdrm_engine {
     uint64_t seed, call_id; int64_t row0;
     const float* xT; bool skinny; bool skinny_launched; int i_start;
   } smp = {false, 0, 0, 0, 0, 0, 1.f, nullptr, nullptr, 0, 0, 0, nullptr, false, false, 0};
+  // sampler row chains: independent row ranges of one sampling call run on their own streams so that one
+  // chain's launch gaps / prologues / tails are filled by another chain's kernels (chain 0 = caller's stream)
+  hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  int n_chains = 1, chain_chunk = 0;
+  bool chains_pending = false;
   // event profiling (bench only)
   bool prof_on = false;
   int prof_cap = 0;
@@ -82,12 +90,16 @@ struct sdrm_engine {
 
 typedef sdrm_engine::SampleStateT SampleState;
 
-enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_COUNT };
+enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_SMP_L0, PC_SMP_HIDDEN,
+                 PC_SMP_OUT, PC_COUNT };
+// the template arguments are <LOADA,LOADB,XFA,XFB,EPI> of gemm_kernel (what rocprofv3 prints after the tile type)
 static const char* kProfNames[PC_COUNT] = {
-    "gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
-    "gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)",
-    "gemm_kernel<0,1,0,0,3> dgrad (prelu' epilogue)", "gemm_kernel<1,1,0,1,4> wgrad (prelu-in, split-K slabs)",
-    "gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)"};
+    "train: gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
+    "train: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)",
+    "train: gemm_kernel<0,0,0,0,3> dgrad (prelu' epilogue)", "train: gemm_kernel<1,1,0,1,4> wgrad (prelu-in, split-K slabs)",
+    "train: gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)",
+    "sample: gemm_kernel<0,0,0,0,0> fwd layer0 (bias table)", "sample: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
+    "sample: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)"};
 
 namespace {
 
@@ -125,17 +137,20 @@ struct Prof { sdrm_engine* e; int cls; double flops; };
 // for 128x128x16): K is only ~350 deep, so a block is mostly prologue/epilogue and per-K-step barrier
 // latency, and what hides that is many co-resident blocks (17 KB of LDS -> 9 per CU), not a big tile.
 typedef TileCfg<64, 64, 2, 2, 4, 16> Cfg0;     //  64x 64x16  (default)
-typedef TileCfg<64, 64, 2, 2, 4, 32> Cfg1;     //  64x 64x32
+typedef TileCfg<64, 64, 2, 2, 2, 32> Cfg1;     //  64x 64x32
 typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
 typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
 typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32: launches too small to fill the chip
 constexpr int N_TILE_CFGS = 5;
 const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
 const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
-// Below ~96 blocks of 64x64 (measured crossover: 1024 rows x 352) a block has its CU to itself and the launch time is one block's chain of
-// dependent MFMAs; 32x32 tiles on the 16-wide MFMA quarter that chain and quadruple the blocks.
-constexpr int SMALL_LAUNCH_BLOCKS = 96;
+// A launch whose 32x32 tiling still fits one work-group per CU (<= 256 blocks) runs on the 16-wide MFMA with
+// 32x32x32 tiles: its time is then one block's chain of dependent MFMAs, a quarter of the 64x64 tile's, and four
+// times as many CUs take part.  Measured crossover (tools/gemm_tune.py, N=K=352): 704 rows 242 blocks faster
+// on 32x32, 1024 rows (352 blocks, a second round on some CUs) faster on 64x64.
+constexpr int SMALL_LAUNCH_BLOCKS32 = 256;
 int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
+int g_chains = -1;     // sampler row chains: -1 = by size, 1..4 forced (SDRM_CHAINS env / sdrm_debug_set_chains)
 int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
 
 int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
@@ -144,7 +159,7 @@ int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
 
 int choose_cfg(int M, int N, int K) {
   int cfg = pick_cfg(M, N, K);
-  if (cfg == 0 && g_force_cfg < 0 && ((M + 63) / 64) * ((N + 63) / 64) <= SMALL_LAUNCH_BLOCKS) cfg = 4;
+  if (cfg == 0 && g_force_cfg < 0 && ((M + 31) / 32) * ((N + 31) / 32) <= SMALL_LAUNCH_BLOCKS32) cfg = 4;
   return cfg;
 }
 
@@ -208,17 +223,17 @@ hipError_t gemm_forward(GemmArgs a, const float* A, int lda, const float* Wc, in
   return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st, pr);
 }
 
-// dgrad: C[M,Kin] = (dC[M,Nout] * Wc[Nout,Kin]) * prelu'(aux)
-hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* Wc, int ldw, int M, int Nout, int Kin,
+// dgrad: C[M,Kin] = (dC[M,Nout] * W[Nout,Kin]) * prelu'(aux), against the transposed copy WT[Kin][Nout] (NT form)
+hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* WT, int ldwt, int M, int Nout, int Kin,
                       float* out, const float* aux, const float* slopeE, float* partial, hipStream_t st, double flops,
                       int cfg) {
   GemmArgs a{};
   a.A = dC; a.lda = lddc; a.limA = M;
-  a.B = Wc; a.ldb = ldw; a.limB = Kin;
+  a.B = WT; a.ldb = ldwt; a.limB = Kin;
   a.C = out; a.ldc = e->WP;
   a.K = Nout; a.kchunk = Nout;
   a.aux = aux; a.ldaux = e->WP; a.slopeE = slopeE; a.slope_partial = partial;
-  return launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st, Prof{e, PC_DGRAD, flops}, cfg);
+  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_DPRELU>(a, M, Kin, 1, st, Prof{e, PC_DGRAD, flops}, cfg);
 }
 
 // wgrad: slab[s][Nout,Kin] = dC[rows s][.,Nout]^T * xf(Act)[rows s][., Kin] ; dbias[s][Nout] = column sums of dC
@@ -257,11 +272,13 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
   const int L = e->L, W = e->W, T = e->T, H = e->H;
   int n = 0;
   auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, const float* src, int src_ld,
-                 size_t slab_stride, int nslabs, float* dst, int dst_ld, int inner = 1) {
+                 size_t slab_stride, int nslabs, float* dst, int dst_ld, int inner = 1, float* dstT = nullptr,
+                 int dstT_ld = 0) {
     Job& j = tab.j[n++];
     j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
     j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
     j.inner = inner;
+    j.dstT = dstT; j.dstT_ld = dstT_ld;
     j.gdst = gbase + off; j.g_ld = flat_ld;
   };
   // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
@@ -271,12 +288,12 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
   // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
   add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
   if (H >= 1) {
-    add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP);
+    add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
     add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
     add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
         dgrad_blocks);
   }
-  add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP);
+  add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
   add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
   tab.n_adam = n;
   // finalize-only job: the one-hot columns of the layer-0 slabs -> dense dC0T[W][TP] for the emb backward
@@ -320,15 +337,36 @@ int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
 
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
 // (its bias / K differ between training and sampling).
-int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st) {
+int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int r0 = 0, int cls = PC_FWD_HIDDEN) {
   const double fl = 2.0 * rows * (double)e->W * e->W;
+  const size_t ro = (size_t)r0 * e->WP;
   for (int k = 1; k <= e->H; ++k) {
     GemmArgs a{};
-    a.C = pre_buf(e, k); a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
-    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1), e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
-                                                 Prof{e, PC_FWD_HIDDEN, fl})));
+    a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
+    HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1) + ro, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
+                                                 Prof{e, cls, fl})));
   }
   return SDRM_OK;
+}
+
+// Chains still running on the auxiliary streams are folded back into `st` before anything else touches
+// the engine's buffers or parameters.
+int join_chains(sdrm_engine* e, hipStream_t st) {
+  if (!e->chains_pending) return SDRM_OK;
+  for (int c = 0; c + 1 < e->n_chains; ++c) {
+    HIP_TRY(e, hipEventRecord(e->ev_join[c], e->aux[c]));
+    HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[c], 0));
+  }
+  e->chains_pending = false;
+  return SDRM_OK;
+}
+
+// Row chains for a sampling call of n rows.  Measured (tools/chain_sweep.py): worthwhile once every chain
+// still has a few hundred rows.
+int chains_for(int n) {
+  if (g_chains >= 1) return g_chains > 4 ? 4 : g_chains;
+  (void)n;
+  return 1;
 }
 
 int upload_schedule(sdrm_engine* e, float beta1, float beta2) {
@@ -397,14 +435,20 @@ int sdrm_debug_set_skinny(int on) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_chains(int chains) {
+  g_chains = chains;
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_tile(int cfg) {
   g_force_cfg = cfg;
   return SDRM_OK;
 }
 
 const char* sdrm_build_info(void) {
-  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (alternates 64x64x32, 64x128x16, 128x128x16), 4 waves, "
-         "LDS double-buffered, distance-2 register prefetch; split-K slabs for wgrad";
+  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (32x32x32 on v_mfma_f32_16x16x4_f32 for launches of <=256 "
+         "such tiles), 4 waves, two LDS stages + register-double-buffered fragments, pipeline pieces in the MFMA shadows, "
+         "k-minor LDS + ds_read_b128 for NT; split-K slabs for wgrad; persistent LDS-resident sampler for widths <= 64";
 }
 
 const char* sdrm_last_error(const sdrm_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -417,6 +461,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
       max_rows > (1 << 22))
     return SDRM_ERR_SHAPE;
   if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
@@ -446,13 +491,14 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->W0c, (size_t)round_up(e->WP, 128) * e->K0)); HIP_TRY(e, dalloc(&e->b0c, e->WP));
   HIP_TRY(e, dalloc(&e->Whc, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
   HIP_TRY(e, dalloc(&e->Woc, (size_t)round_up(e->LP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
+  HIP_TRY(e, dalloc(&e->WhcT, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->WocT, (size_t)round_up(e->WP, 128) * e->LP));
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
   HIP_TRY(e, dalloc(&e->dA, MP * e->WP)); HIP_TRY(e, dalloc(&e->dB, MP * e->WP));
-  HIP_TRY(e, dalloc(&e->X, MP * e->LP));
+  HIP_TRY(e, dalloc(&e->X, MP * e->LP)); HIP_TRY(e, dalloc(&e->Us, MP * e->LP));
   HIP_TRY(e, dalloc(&e->slab0, (size_t)S_MAX * e->WP * e->K0)); HIP_TRY(e, dalloc(&e->db0s, (size_t)S_MAX * e->WP));
   HIP_TRY(e, dalloc(&e->slabO, (size_t)S_MAX * e->LP * e->WP)); HIP_TRY(e, dalloc(&e->dbOs, (size_t)S_MAX * e->LP));
   if (H >= 1) {
@@ -464,6 +510,11 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
   HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (int c = 0; c < 3; ++c) {
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->aux[c], hipStreamNonBlocking));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming));
+  }
   int rc = upload_schedule(e, 1e-4f, 0.02f);
   if (rc) return rc;
   rc = upload_temb(e);
@@ -477,10 +528,16 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->dB, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+  (void)hipDeviceSynchronize();
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  for (int c = 0; c < 3; ++c) {
+    if (e->ev_join[c]) (void)hipEventDestroy(e->ev_join[c]);
+    if (e->aux[c]) (void)hipStreamDestroy(e->aux[c]);
+  }
   delete e;
   return SDRM_OK;
 }
@@ -504,6 +561,7 @@ int sdrm_get_schedule(const sdrm_engine* e, float* b, float* a, float* ab) {
 int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream) {
   if (!e || !flat) return fail(e, SDRM_ERR_ARG, "sdrm_set_params: null pointer");
   hipStream_t st = (hipStream_t)stream;
+  if (int jr = join_chains(e, st)) return jr;
   HIP_TRY(e, hipMemcpyAsync(e->p, flat, e->P * 4, hipMemcpyDeviceToDevice, st));
   return launch_adam(e, nullptr, 0.f, 0, st);  // re-pack only
 }
@@ -556,6 +614,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: EXPLICIT mode needs noise, t and keep");
   if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
   hipStream_t st = (hipStream_t)stream;
+  if (int jr = join_chains(e, st)) return jr;
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   e->fwd_done = false;
 
@@ -630,14 +689,14 @@ int sdrm_train_backward_upper(sdrm_engine* e, const double* sums, float* grad, f
                                    e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
   float* dcur = e->dA;
   float* dnext = e->dB;
-  HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->Woc, e->WP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
+  HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->WocT, e->LP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
                         e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO, cfg_d));
   // shared hidden layer, applications H..1
   for (int k = H; k >= 1; --k) {
     HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dcur, e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
                                      kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
                                      e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
-    HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
+    HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->WhcT, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
                           slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
     float* tmp = dcur; dcur = dnext; dnext = tmp;
   }
@@ -706,6 +765,7 @@ int sdrm_grad_buckets(const sdrm_engine* e, int64_t* lower_len, int64_t* upper_l
 
 int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
   if (!e) return SDRM_ERR_ARG;
+  if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
   e->adam_t += 1;
   return launch_adam(e, grad, lr, 1, (hipStream_t)stream);
 }
@@ -733,6 +793,7 @@ int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
 static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_uniform, int n, int mode,
                         const uint8_t* keep, uint64_t seed, uint64_t step, int64_t row0, float* out, int ldout,
                         int cols_valid, hipStream_t st) {
+  if (int jr = join_chains(e, st)) return jr;
   const int MP = round_up(n, BM);
   PrepFwdArgs pa{};
   pa.x = x; pa.t = t; pa.t_uniform = t_uniform; pa.keep = keep; pa.U = e->U;
@@ -805,8 +866,12 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
   if (multires && n > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: multi-resolution n > max_rows");
   hipStream_t st = (hipStream_t)stream;
+  if (int jr = join_chains(e, st)) return jr;
   const int T = e->T, L = e->L, MP = round_up(n, BM);
   e->fwd_done = false;
+  e->n_chains = chains_for(n);
+  e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
+  e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
   int rc = emb_tables(e, true, st);
   if (rc) return rc;
   int i_start = T;
@@ -851,7 +916,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   }
   SampleInitArgs ia{};
   ia.xT = xT; ia.keep = keep; ia.Tj = multires ? e->Tj_dev : nullptr; ia.rowid = multires ? e->rowid_dev : nullptr;
-  ia.X = e->X; ia.U = e->U; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->K0; ia.MP = MP; ia.T = T;
+  ia.X = e->X; ia.U = e->Us; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->LP; ia.MP = MP; ia.T = T;
   ia.mode = mode; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
   dim3 grid((e->LP / 2 + 255) / 256, MP);
@@ -904,38 +969,47 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     s.i_next = s.i_next > count ? s.i_next - count : 0;
     return SDRM_OK;
   }
+  if (e->n_chains > 1 && !e->chains_pending) {       // fork: the other chains start after everything queued on st so far
+    HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+    for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
+    e->chains_pending = true;                        // joined lazily by the next entry point that needs the result
+  }
   for (int done = 0; done < count && s.i_next >= 1; ++done, --s.i_next) {
     const int i = s.i_next;
     const int na = e->smp_nact[i];                 // active prefix at this step
-    if (na == 0) continue;
-    const int MP = round_up(na, BM);
-    {
-      GemmArgs a{};
-      a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
-      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
-                                                  Prof{e, PC_FWD_L0, 2.0 * na * (double)e->W * (e->L + e->T)})));
+    for (int c = 0; c < e->n_chains; ++c) {
+      const int s0 = c * e->chain_chunk, s1 = std::min(na, s0 + e->chain_chunk);
+      if (s1 <= s0) break;
+      hipStream_t sc = c == 0 ? st : e->aux[c - 1];
+      const int rows = s1 - s0, MP = round_up(rows, BM);
+      {
+        GemmArgs a{};
+        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->Us + (size_t)s0 * e->LP, e->LP, e->W0c, e->K0, MP, e->WP, e->LP, sc,
+                                                    Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)})));
+      }
+      int rc = hidden_forward(e, MP, rows, sc, s0, PC_SMP_HIDDEN);
+      if (rc) return rc;
+      {
+        GemmArgs a{};
+        a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+        a.rows_valid = MP; a.cols_valid = e->LP;
+        HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+                                                          e->LP, e->WP, sc, Prof{e, PC_SMP_OUT, 2.0 * rows * (double)e->L * e->W})));
+      }
+      ReverseArgs ra{};
+      ra.X = e->X; ra.Y = e->Y; ra.U = e->Us;
+      ra.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
+      ra.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
+      ra.Tj = s.multires ? e->Tj_dev : nullptr;
+      ra.rowid = s.multires ? e->rowid_dev : nullptr;
+      ra.s0 = s0; ra.n = s1; ra.L = L; ra.LP = e->LP; ra.K0 = e->LP; ra.step_i = i; ra.nd = s.nd;
+      reverse_coeffs(e, i, ra.c1, ra.sqrt_alpha, ra.sqrt_beta);
+      ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
+      ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
+      hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, rows), dim3(256), 0, sc, ra);
+      HIP_TRY(e, hipGetLastError());
     }
-    int rc = hidden_forward(e, MP, na, st);
-    if (rc) return rc;
-    {
-      GemmArgs a{};
-      a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
-      a.rows_valid = MP; a.cols_valid = e->LP;
-      HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
-                                                        Prof{e, PC_FWD_OUT, 2.0 * na * (double)e->L * e->W})));
-    }
-    ReverseArgs ra{};
-    ra.X = e->X; ra.Y = e->Y; ra.U = e->U;
-    ra.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
-    ra.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
-    ra.Tj = s.multires ? e->Tj_dev : nullptr;
-    ra.rowid = s.multires ? e->rowid_dev : nullptr;
-    ra.n = na; ra.L = L; ra.LP = e->LP; ra.K0 = e->K0; ra.step_i = i; ra.nd = s.nd;
-    reverse_coeffs(e, i, ra.c1, ra.sqrt_alpha, ra.sqrt_beta);
-    ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
-    ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
-    hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, na), dim3(256), 0, st, ra);
-    HIP_TRY(e, hipGetLastError());
   }
   return SDRM_OK;
 }
@@ -946,6 +1020,7 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (!e || !out) return SDRM_ERR_ARG;
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
   if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
+  if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
   if (e->smp.skinny)   // the persistent kernel wrote dense [n,L] rows in original order
     HIP_TRY(e, hipMemcpyAsync(out, e->X, (size_t)e->smp.n * e->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   else
@@ -1000,6 +1075,7 @@ int sdrm_profile_begin(sdrm_engine* e, int capacity) {
 int sdrm_profile_end(sdrm_engine* e, void* stream) {
   if (!e) return SDRM_ERR_ARG;
   e->prof_on = false;
+  if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
   HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
   for (size_t i = 0; i < e->prof_cls.size(); ++i) {
     float ms = 0.f;
