@@ -111,14 +111,16 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
                        const sdrm_train_randoms* rnd, uint64_t seed, uint64_t step, float noise_divider,
                        double* sums, void* stream);
 int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream);
-/* The same backward in two halves (sdrm_train_backward == upper then lower), for callers that overlap the
- * gradient exchange with compute.  `upper` runs the seeds and every GEMM down to the last dgrad and finalises
- * flat[lower_len .. P) (layer-0 slope, hidden and output layer); `lower` runs the layer-0 weight gradient and the
- * embedding backward and finalises flat[0 .. lower_len).  A data-parallel caller starts the all-reduce of the
- * upper bucket on another stream between the two calls.  sdrm_grad_buckets returns the two lengths. */
-int sdrm_train_backward_upper(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream);
-int sdrm_train_backward_lower(sdrm_engine* e, float* grad, void* stream);
-int sdrm_grad_buckets(const sdrm_engine* e, int64_t* lower_len, int64_t* upper_len);
+/* Phase 2 in two calls, for callers that overlap the gradient exchange with the backward (no reference
+ * counterpart: the reference is single-device).  `begin` runs the loss seeds, the dgrad chain, the layer-0
+ * weight gradient and the embedding backward and finalises the FIRST bucket of `grad` in `stream` order; `finish`
+ * runs the weight gradients of the upper layers and finalises the SECOND bucket.  sdrm_grad_buckets returns the two [offset, length) ranges of the flat gradient (first: emb_layer.*,
+ * dnn.0.weight, dnn.0.bias; second: everything from dnn.1 (the first PReLU slope) on).  Same `grad` in both calls.
+ * sdrm_train_backward == begin + finish. */
+int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream);
+int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream);
+int sdrm_grad_buckets(const sdrm_engine* e, int64_t* first_off, int64_t* first_len, int64_t* second_off,
+                      int64_t* second_len);
 int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream);
 /* Single-GPU convenience: (1)+(2)+(3) back to back on `stream`. */
 int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,

@@ -35,9 +35,9 @@ SIGNATURES = {
     "sdrm_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, C.POINTER(TrainRandoms), c_uint64,
                                    c_uint64, c_float, c_void_p, c_void_p]),
     "sdrm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sdrm_train_backward_upper": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sdrm_train_backward_lower": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "sdrm_grad_buckets": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int64)]),
+    "sdrm_train_backward_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "sdrm_train_backward_finish": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_grad_buckets": (c_int, [c_void_p, C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int64), C.POINTER(c_int64)]),
     "sdrm_adam_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "sdrm_train_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, C.POINTER(TrainRandoms), c_uint64, c_uint64,
                                 c_float, c_void_p, c_void_p]),

@@ -22,7 +22,7 @@ namespace {
 constexpr int BM = 64, BN = 64;     // row padding granule = rows of the default tile (the 128-row alternates read into
                                     // the slack every buffer carries, and write rows nobody reads)
 constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
-constexpr int TARGET_BLOCKS = 1024; // work-groups a wgrad launch aims for (4 per CU)
+int g_wgrad_blocks = 1024;           // work-groups a wgrad launch aims for (SDRM_WGRAD_BLOCKS env: tuning aid)
 constexpr int LOSS_BLOCKS = 256;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -42,7 +42,7 @@ struct sdrm_engine {
   float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
-  float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *dB = nullptr, *X = nullptr;
+  float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *X = nullptr;
   float *slab0 = nullptr, *slabH = nullptr, *slabO = nullptr, *db0s = nullptr, *dbHs = nullptr, *dbOs = nullptr;
   float *alpha_part = nullptr;
   int alpha_part_stride = 0;
@@ -62,9 +62,8 @@ struct sdrm_engine {
   const float* cur_x0 = nullptr;
   bool fwd_done = false;
   int last_S = 1, last_dgrad_blocks = 0;
-  bool bwd_upper_done = false;
-  float* bwd_dcur = nullptr;
-  int bwd_S0 = 1, bwd_kc0 = 0, bwd_SH = 1, bwd_SO = 1, bwd_dgrad_blocks = 0;
+  bool bwd_begun = false;
+  int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
@@ -127,6 +126,7 @@ hipError_t dalloc(Tp** p, size_t n) {
 }
 
 float* pre_buf(sdrm_engine* e, int k) { return e->pre + (size_t)k * e->MPmax * e->WP; }
+float* dpre_buf(sdrm_engine* e, int k) { return e->dA + (size_t)k * e->MPmax * e->WP; }   // d loss / d pre-activation k
 const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? e->off_a0 : e->off_ah); }
 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
@@ -255,7 +255,7 @@ void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
   const int c = pick_cfg(Nout, Kin, 4096);
   const int tiles = ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
   const int BK = 32;
-  int want = TARGET_BLOCKS / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
+  int want = g_wgrad_blocks / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
   if (max_by_rows < 1) max_by_rows = 1;
   S = want < 1 ? 1 : want;
@@ -352,6 +352,7 @@ int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int r0 = 0,
 // Chains still running on the auxiliary streams are folded back into `st` before anything else touches
 // the engine's buffers or parameters.
 int join_chains(sdrm_engine* e, hipStream_t st) {
+  e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
   if (!e->chains_pending) return SDRM_OK;
   for (int c = 0; c + 1 < e->n_chains; ++c) {
     HIP_TRY(e, hipEventRecord(e->ev_join[c], e->aux[c]));
@@ -462,6 +463,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     return SDRM_ERR_SHAPE;
   if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
   if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) g_wgrad_blocks = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
@@ -497,7 +499,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
-  HIP_TRY(e, dalloc(&e->dA, MP * e->WP)); HIP_TRY(e, dalloc(&e->dB, MP * e->WP));
+  HIP_TRY(e, dalloc(&e->dA, (size_t)(H + 1) * MP * e->WP));   // dpre_buf(0..H)
   HIP_TRY(e, dalloc(&e->X, MP * e->LP)); HIP_TRY(e, dalloc(&e->Us, MP * e->LP));
   HIP_TRY(e, dalloc(&e->slab0, (size_t)S_MAX * e->WP * e->K0)); HIP_TRY(e, dalloc(&e->db0s, (size_t)S_MAX * e->WP));
   HIP_TRY(e, dalloc(&e->slabO, (size_t)S_MAX * e->LP * e->WP)); HIP_TRY(e, dalloc(&e->dbOs, (size_t)S_MAX * e->LP));
@@ -527,7 +529,7 @@ int sdrm_destroy(sdrm_engine* e) {
   if (!e) return SDRM_ERR_ARG;
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
-                  e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->dB, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
+                  e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
                   e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -659,15 +661,20 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   return SDRM_OK;
 }
 
-// Backward in two halves so that a data-parallel caller can all-reduce the UPPER gradient bucket
-// (flat[off_a0 ..): slopes, hidden and output layer - final once the last dgrad is done) while the lower half
-// (layer-0 wgrad, its slab reduction, the embedding backward -> flat[0 .. off_a0)) is still running.
-int sdrm_train_backward_upper(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+// Backward in two calls, so that a data-parallel caller can all-reduce one gradient bucket while the other is
+// still being computed.  `begin` runs the chain every other kernel waits for (loss seeds, the dgrads down to
+// layer 0), then the layer-0 weight gradient, its slab reduction and the small, latency-bound embedding
+// backward: when it returns, the FIRST bucket (flat[0, off_a0): emb_layer.*, dnn.0.weight/bias) is final in
+// stream order.  `finish` runs the weight gradients of the upper layers - two thirds of the wgrad flops,
+// nothing but Adam depends on them - and reduces the second bucket (slopes, hidden and output layer).
+// (Forking the upper wgrads to a second stream so that they also overlap the embedding backward on ONE GPU was
+// measured: the two cross-stream event waits cost more than the ~45 us they hide, 642 vs 627 us per step.)
+int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
   if (!e) return SDRM_ERR_ARG;
   if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
   hipStream_t st = (hipStream_t)stream;
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
-  e->bwd_upper_done = false;
+  e->bwd_begun = false;
   SeedArgs sa{};
   sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
@@ -683,52 +690,22 @@ int sdrm_train_backward_upper(sdrm_engine* e, const double* sums, float* grad, f
   // every dgrad writes [MP,WP]: one tile shape for all of them, so the slope partial counts agree
   const int cfg_d = choose_cfg(MP, e->WP, e->WP);
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
-  // output layer
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
-  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, kcO,
-                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
-  float* dcur = e->dA;
-  float* dnext = e->dB;
-  HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->WocT, e->LP, MP, e->LP, e->WP, dcur, pre_buf(e, H), slope_ptr(e, H),
+  const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
+  // dgrad chain: dpre[k] = gradient w.r.t. pre-activation k (kept for the deferred weight gradients)
+  HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->WocT, e->LP, MP, e->LP, e->WP, dpre_buf(e, H), pre_buf(e, H), slope_ptr(e, H),
                         e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO, cfg_d));
-  // shared hidden layer, applications H..1
-  for (int k = H; k >= 1; --k) {
-    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dcur, e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
-                                     kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
-                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
-    HIP_TRY(e, gemm_dgrad(e, dcur, e->WP, e->WhcT, e->WP, MP, e->WP, e->WP, dnext, pre_buf(e, k - 1),
+  for (int k = H; k >= 1; --k)
+    HIP_TRY(e, gemm_dgrad(e, dpre_buf(e, k), e->WP, e->WhcT, e->WP, MP, e->WP, e->WP, dpre_buf(e, k - 1), pre_buf(e, k - 1),
                           slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
-    float* tmp = dcur; dcur = dnext; dnext = tmp;
-  }
-  // the flat gradient is written where the caller wants it (a DDP bucket) - no copy afterwards
+  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
+  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                  Prof{e, PC_WGRAD_L0, fl0})));
+  // first bucket.  The flat gradient is written where the caller wants it (a DDP bucket) - no copy afterwards.
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
   JobTable tab;
   build_jobs(e, tab, S0, SH, SO, dgrad_blocks, gout);
-  // upper bucket = every job at or above the layer-0 slope in the flat order
-  JobTable up{};
-  for (int j = 0; j < tab.n; ++j)
-    if (tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P) up.j[up.n++] = tab.j[j];
-  hipLaunchKernelGGL(k_grad_finalize, dim3(512, up.n), dim3(256), 0, st, up);
-  HIP_TRY(e, hipGetLastError());
-  e->bwd_dcur = dcur; e->bwd_S0 = S0; e->bwd_kc0 = kc0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
-  e->bwd_upper_done = true;
-  return SDRM_OK;
-}
-
-int sdrm_train_backward_lower(sdrm_engine* e, float* grad, void* stream) {
-  if (!e) return SDRM_ERR_ARG;
-  if (!e->fwd_done || !e->bwd_upper_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward_lower: upper half not run");
-  hipStream_t st = (hipStream_t)stream;
-  const int B = e->cur_B, MP = e->cur_MP;
-  float* gout = grad ? grad : e->g;
-  if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_lower: different gradient buffer than the upper half");
-  const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
-  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
-  HIP_TRY(e, (gemm_wgrad<XF_NONE>(e->bwd_dcur, e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, e->bwd_S0, e->bwd_kc0, e->slab0,
-                                  e->db0s, st, Prof{e, PC_WGRAD_L0, fl0})));
-  JobTable tab;
-  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
   JobTable lo{};
   for (int j = 0; j < tab.n; ++j)
     if (!(tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P)) lo.j[lo.n++] = tab.j[j];
@@ -746,20 +723,47 @@ int sdrm_train_backward_lower(sdrm_engine* e, float* grad, void* stream) {
     hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
     HIP_TRY(e, hipGetLastError());
   }
-  e->bwd_upper_done = false;
+  e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
+  e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+  e->bwd_begun = true;
+  return SDRM_OK;
+}
+
+int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done || !e->bwd_begun) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward_finish: sdrm_train_backward_begin not run");
+  hipStream_t st = (hipStream_t)stream;
+  float* gout = grad ? grad : e->g;
+  if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_finish: different gradient buffer than begin");
+  const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
+  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
+  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
+                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
+  for (int k = H; k >= 1; --k)
+    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
+                                     e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
+                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
+  JobTable tab;
+  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
+  JobTable up{};
+  for (int j = 0; j < tab.n; ++j)
+    if (tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P) up.j[up.n++] = tab.j[j];
+  hipLaunchKernelGGL(k_grad_finalize, dim3(512, up.n), dim3(256), 0, st, up);
+  HIP_TRY(e, hipGetLastError());
+  e->bwd_begun = false;
   return SDRM_OK;
 }
 
 int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
-  int rc = sdrm_train_backward_upper(e, sums, grad, loss, stream);
+  int rc = sdrm_train_backward_begin(e, sums, grad, loss, stream);
   if (rc) return rc;
-  return sdrm_train_backward_lower(e, grad, stream);
+  return sdrm_train_backward_finish(e, grad, stream);
 }
 
-int sdrm_grad_buckets(const sdrm_engine* e, int64_t* lower_len, int64_t* upper_len) {
-  if (!e || !lower_len || !upper_len) return SDRM_ERR_ARG;
-  *lower_len = e->off_a0;
-  *upper_len = e->P - e->off_a0;
+int sdrm_grad_buckets(const sdrm_engine* e, int64_t* first_off, int64_t* first_len, int64_t* second_off, int64_t* second_len) {
+  if (!e || !first_off || !first_len || !second_off || !second_len) return SDRM_ERR_ARG;
+  *first_off = 0; *first_len = e->off_a0;
+  *second_off = e->off_a0; *second_len = e->P - e->off_a0;
   return SDRM_OK;
 }
 

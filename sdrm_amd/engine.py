@@ -151,21 +151,23 @@ class Engine:
                     "sdrm_train_backward")
         return self._loss
 
-    def train_backward_upper(self, sums=None, grad=None):
-        """First half of phase 2: finalises grad[lower_len:] (see `grad_buckets`)."""
+    def train_backward_begin(self, sums=None, grad=None):
+        """Phase 2, first call: on return the FIRST bucket of `grad` (see `grad_buckets`) is final in stream order;
+        the upper layers' weight gradients are left to `train_backward_finish`."""
         sums = self._sums if sums is None else sums
-        self._check(self.lib.sdrm_train_backward_upper(self._h, _ptr(sums), _ptr(grad), _ptr(self._loss), _stream()),
-                    "sdrm_train_backward_upper")
+        self._check(self.lib.sdrm_train_backward_begin(self._h, _ptr(sums), _ptr(grad), _ptr(self._loss), _stream()),
+                    "sdrm_train_backward_begin")
         return self._loss
 
-    def train_backward_lower(self, grad=None):
-        """Second half of phase 2: layer-0 weight gradient + embedding backward -> grad[:lower_len]."""
-        self._check(self.lib.sdrm_train_backward_lower(self._h, _ptr(grad), _stream()), "sdrm_train_backward_lower")
+    def train_backward_finish(self, grad=None):
+        """Phase 2, second call: upper-layer weight gradients, then the SECOND bucket is final."""
+        self._check(self.lib.sdrm_train_backward_finish(self._h, _ptr(grad), _stream()), "sdrm_train_backward_finish")
 
     def grad_buckets(self):
-        lo, up = C.c_int64(), C.c_int64()
-        self._check(self.lib.sdrm_grad_buckets(self._h, C.byref(lo), C.byref(up)), "sdrm_grad_buckets")
-        return int(lo.value), int(up.value)
+        """((offset, length) of the first bucket, (offset, length) of the second) in the flat gradient."""
+        v = [C.c_int64() for _ in range(4)]
+        self._check(self.lib.sdrm_grad_buckets(self._h, *[C.byref(x) for x in v]), "sdrm_grad_buckets")
+        return (int(v[0].value), int(v[1].value)), (int(v[2].value), int(v[3].value))
 
     def adam_step(self, lr, grad=None):
         """Phase 3: coupled-L2 Adam (:309,:337) at the caller's per-epoch lr (:316)."""

@@ -54,14 +54,15 @@ class ShardedTrainer:
             noise, t, keep = explicit
             e.train_forward(x0_local, noise=noise, t=t, keep=keep, nd=nd, row0=row0, sums=self.sums)
         dist.all_reduce(self.sums, op=dist.ReduceOp.SUM, group=self.group)
-        if self.overlap and hasattr(e, "train_backward_upper"):
-            # bucketed exchange: the upper bucket (slopes, hidden and output layer; final after the last dgrad)
-            # is all-reduced on the collective's own stream while the layer-0 / embedding backward still runs
-            lower = e.grad_buckets()[0]
-            loss = e.train_backward_upper(sums=self.sums, grad=self.grad)
-            work = dist.all_reduce(self.grad[lower:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            e.train_backward_lower(grad=self.grad)
-            dist.all_reduce(self.grad[:lower], op=dist.ReduceOp.SUM, group=self.group)
+        if self.overlap and hasattr(e, "train_backward_begin"):
+            # bucketed exchange: the first bucket (embedding + layer 0; final once the layer-0 weight gradient and
+            # the embedding backward are done) is all-reduced on the collective's own stream while the upper
+            # layers' weight gradients (two thirds of the wgrad flops) are computed
+            (o0, n0), (o1, n1) = e.grad_buckets()
+            loss = e.train_backward_begin(sums=self.sums, grad=self.grad)
+            work = dist.all_reduce(self.grad[o0:o0 + n0], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            e.train_backward_finish(grad=self.grad)
+            dist.all_reduce(self.grad[o1:o1 + n1], op=dist.ReduceOp.SUM, group=self.group)
             work.wait()
         else:
             loss = e.train_backward(sums=self.sums, grad=self.grad)

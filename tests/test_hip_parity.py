@@ -376,15 +376,15 @@ def test_sharded_equals_single(engine_cls):
         e.train_forward(x0[r0:r0 + rows], seed=seed, step=step, row0=r0, sums=s)
         engs.append(e); sums.append(s)
     total = sums[0] + sums[1]
-    lower, upper = engs[0].grad_buckets()
-    assert lower + upper == engs[0].P
+    (o0, n0), (o1, n1) = engs[0].grad_buckets()
+    assert o0 == 0 and o1 == n0 and n0 + n1 == engs[0].P
     for k, e in enumerate(engs):
         g = torch.full((e.P,), float("nan"), dtype=torch.float32, device="cuda")
-        if k == 0:                                   # the bucketed form must fill exactly its two halves
-            e.train_backward_upper(sums=total, grad=g)
+        if k == 0:                                   # the bucketed form must fill exactly its two buckets
+            e.train_backward_begin(sums=total, grad=g)
             torch.cuda.synchronize()
-            assert bool(torch.isnan(g[:lower]).all()) and bool(torch.isfinite(g[lower:]).all())
-            e.train_backward_lower(grad=g)
+            assert bool(torch.isfinite(g[:n0]).all()) and bool(torch.isnan(g[o1:]).all())
+            e.train_backward_finish(grad=g)
         else:
             e.train_backward(sums=total, grad=g)
         grads.append(g)

@@ -65,22 +65,22 @@ class OraclePhases:
         grad.copy_(torch.cat([grads[n].reshape(-1) for n in self.names]))
         return torch.tensor(0.5 * (A + C) / den)
 
-    # the two-bucket form of phase 2 (sdrm_train_backward_upper / _lower)
+    # the two-bucket form of phase 2 (sdrm_train_backward_begin / _finish)
     def grad_buckets(self):
         shapes = synth.param_shapes(L, W, T, H)
-        lower = sum(int(np.prod(shapes[n])) for n in ("emb_layer.weight", "emb_layer.bias", "dnn.0.weight", "dnn.0.bias"))
-        return lower, self.P - lower
+        first = sum(int(np.prod(shapes[n])) for n in ("emb_layer.weight", "emb_layer.bias", "dnn.0.weight", "dnn.0.bias"))
+        return (0, first), (first, self.P - first)
 
-    def train_backward_upper(self, sums=None, grad=None):
+    def train_backward_begin(self, sums=None, grad=None):
         full = torch.zeros(self.P)
         loss = self.train_backward(sums=sums, grad=full)
-        lower = self.grad_buckets()[0]
-        grad[lower:] = full[lower:]
-        self._lower = full[:lower].clone()
+        first = self.grad_buckets()[0][1]
+        grad[:first] = full[:first]
+        self._second = full[first:].clone()
         return loss
 
-    def train_backward_lower(self, grad=None):
-        grad[:self._lower.numel()] = self._lower
+    def train_backward_finish(self, grad=None):
+        grad[self.P - self._second.numel():] = self._second
 
     def adam_step(self, lr, grad=None):
         shapes = synth.param_shapes(L, W, T, H)
