@@ -84,6 +84,18 @@ __global__ __launch_bounds__(256) void k_emb_tables(const EmbTabArgs a) {
   emb_tables_row(a, blockIdx.x, sh);
 }
 
+// four consecutive columns of an unpadded [rows, L] matrix (vector load when rows are 16-B aligned)
+__device__ __forceinline__ float4 load4_unpadded(const float* __restrict__ x, int r, int c, int L) {
+  const float* p = x + (size_t)r * L + c;
+  if ((L & 3) == 0) return *reinterpret_cast<const float4*>(p);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < L) v.x = p[0];
+  if (c + 1 < L) v.y = p[1];
+  if (c + 2 < L) v.z = p[2];
+  if (c + 3 < L) v.w = p[3];
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Train-step staging: q_sample (:203) + the three dropout-ed inputs (:100) + one-hot(t) columns.
 //   U[0*B + r] = 2*keep1 * (sqrt(abar[t]) x0 + (1-abar[t]) eps)      pass P (:328,:331)
@@ -97,23 +109,26 @@ struct PrepTrainArgs {
   float* U; int* tdev;
   int B, L, LP, K0, T, MP;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
-  EmbTabArgs emb; int emb_row0;   // grid rows >= emb_row0 build the step's embedding tables (independent work,
-                                  // merged here so it runs beside the staging instead of as its own launch)
+  EmbTabArgs emb; int emb_row0;   // staged + zero-pad rows; the first `emb_blocks` blocks build the step's embedding
+  int emb_blocks;                 // tables (independent work, merged here so it runs beside the staging)
 };
 
 __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
   extern __shared__ float sh[];
-  const int r = blockIdx.y;
-  if (r >= a.emb_row0) {
-    if (blockIdx.x == 0) emb_tables_row(a.emb, r - a.emb_row0, sh);
+  if ((int)blockIdx.x < a.emb_blocks) {   // leading blocks (dispatched first: each is a ~10 us serial chain, the
+    emb_tables_row(a.emb, (int)blockIdx.x, sh);   // staging blocks behind them fill the rest of the chip meanwhile)
     return;
   }
-  const int q = blockIdx.x * 256 + threadIdx.x;  // column pair
-  const int c = 2 * q;
-  if (c >= a.K0) return;
+  // one thread per group of four columns of one staged row triple (16-byte stores; the row's t is drawn once
+  // per thread instead of once per column pair)
+  const int QP = a.K0 >> 2;
+  const int64_t i = (int64_t)((int)blockIdx.x - a.emb_blocks) * 256 + threadIdx.x;
+  const int r = (int)(i / QP);
+  const int c = 4 * (int)(i - (int64_t)r * QP);
+  if (r >= a.emb_row0) return;
   if (r >= a.B) {  // zero pad rows
     const int row = 3 * a.B + (r - a.B);
-    if (row < a.MP) *reinterpret_cast<float2*>(a.U + (size_t)row * a.K0 + c) = make_float2(0.f, 0.f);
+    if (row < a.MP) *reinterpret_cast<float4*>(a.U + (size_t)row * a.K0 + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
   int tt;
@@ -124,27 +139,31 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
     tt = 1 + (int)bounded(w.x, (uint32_t)a.T);
   }
   tt = min(max(tt, 0), a.T);
-  if (q == 0) a.tdev[r] = tt;
-  float2 oP = make_float2(0.f, 0.f), oS = oP, oQ = oP;
+  if (c == 0) a.tdev[r] = tt;
+  float vP[4] = {0.f, 0.f, 0.f, 0.f}, vS[4] = {0.f, 0.f, 0.f, 0.f}, vQ[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < a.LP) {
     if (c < a.L) {
       const float sa = a.sqrt_ab[tt], om = a.one_minus_ab[tt];
-      float e[2] = {0.f, 0.f};
-      uint32_t bits = 0;
+      const float4 X = load4_unpadded(a.x0, r, c, a.L);
+      const float x_[4] = {X.x, X.y, X.z, X.w};
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      uint32_t bits[2] = {0u, 0u};
       if (a.mode != 0) {
-        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)q, PURPOSE_TRAIN_ELEM, a.step, a.seed_lo,
-                                   a.seed_hi);
-        box_muller(w.x, w.y, e[0], e[1]);
-        e[0] *= a.nd; e[1] *= a.nd;
-        bits = w.z;
-      }
-      float vP[2] = {0.f, 0.f}, vS[2] = {0.f, 0.f}, vQ[2] = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        for (int h = 0; h < 2; ++h) {   // the counter is the column PAIR (same stream as the 2-column form)
+          const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)(c / 2 + h), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo,
+                                     a.seed_hi);
+          box_muller(w.x, w.y, e[2 * h], e[2 * h + 1]);
+          e[2 * h] *= a.nd; e[2 * h + 1] *= a.nd;
+          bits[h] = w.z;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
         const int cc = c + j;
         if (cc < a.L) {
           const size_t idx = (size_t)r * a.L + cc;
-          const float x = a.x0[idx];
+          const float x = x_[j];
           bool k1, k2, k3;
           float ee;
           if (a.mode == 0) {
@@ -153,7 +172,7 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
             k1 = a.keep[idx] != 0; k2 = a.keep[BL + idx] != 0; k3 = a.keep[2 * BL + idx] != 0;
           } else {
             ee = e[j];
-            const uint32_t bb = bits >> (8 * j);
+            const uint32_t bb = bits[j >> 1] >> (8 * (j & 1));
             k1 = bb & 1u; k2 = (bb >> 1) & 1u; k3 = (bb >> 2) & 1u;
           }
           const float xp = sa * x + om * ee;
@@ -163,16 +182,15 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
           vQ[j] = k3 ? 2.f * xq : 0.f;
         }
       }
-      oP = make_float2(vP[0], vP[1]); oS = make_float2(vS[0], vS[1]); oQ = make_float2(vQ[0], vQ[1]);
     }
   } else {
     const int h = c - a.LP;  // one-hot region
-    const float2 oh = make_float2(h == tt ? 1.f : 0.f, (h + 1) == tt ? 1.f : 0.f);
-    oP = oh; oS = oh; oQ = oh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vP[j] = vS[j] = vQ[j] = ((h + j) == tt) ? 1.f : 0.f;
   }
-  *reinterpret_cast<float2*>(a.U + (size_t)r * a.K0 + c) = oP;
-  *reinterpret_cast<float2*>(a.U + (size_t)(a.B + r) * a.K0 + c) = oS;
-  *reinterpret_cast<float2*>(a.U + (size_t)(2 * a.B + r) * a.K0 + c) = oQ;
+  *reinterpret_cast<float4*>(a.U + (size_t)r * a.K0 + c) = make_float4(vP[0], vP[1], vP[2], vP[3]);
+  *reinterpret_cast<float4*>(a.U + (size_t)(a.B + r) * a.K0 + c) = make_float4(vS[0], vS[1], vS[2], vS[3]);
+  *reinterpret_cast<float4*>(a.U + (size_t)(2 * a.B + r) * a.K0 + c) = make_float4(vQ[0], vQ[1], vQ[2], vQ[3]);
 }
 
 // Staging for a plain forward / reverse step on caller rows: U = 2*keep*x | one-hot(t).
@@ -236,18 +254,6 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return s;
 }
 
-// four consecutive columns of an unpadded [rows, L] matrix (vector load when rows are 16-B aligned)
-__device__ __forceinline__ float4 load4_unpadded(const float* __restrict__ x, int r, int c, int L) {
-  const float* p = x + (size_t)r * L + c;
-  if ((L & 3) == 0) return *reinterpret_cast<const float4*>(p);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < L) v.x = p[0];
-  if (c + 1 < L) v.y = p[1];
-  if (c + 2 < L) v.z = p[2];
-  if (c + 3 < L) v.w = p[3];
-  return v;
-}
-
 __global__ __launch_bounds__(256) void k_loss_partials(const LossArgs a) {
   __shared__ double sh[4];
   double sD = 0, sC = 0, sR = 0, sR2 = 0;
@@ -283,6 +289,8 @@ __global__ __launch_bounds__(256) void k_loss_partials(const LossArgs a) {
   }
 }
 
+// The five global sums, in block order (deterministic).  (Folding this into the last block of k_loss_partials
+// through a ticket was measured: 6.4 us of fences and a serial tail against 4.8 us for this launch.)
 __global__ __launch_bounds__(256) void k_loss_sums(const double* part, int nblk, double count, double* sums) {
   __shared__ double sh[4];
   double v[4] = {0, 0, 0, 0};

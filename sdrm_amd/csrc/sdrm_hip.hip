@@ -631,8 +631,9 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   {
     pa.emb = emb_args(e, false);
     pa.emb_row0 = B + (MP - 3 * B);
-    dim3 grid((e->K0 / 2 + 255) / 256, pa.emb_row0 + e->T + 1);
-    hipLaunchKernelGGL(k_prep_train, grid, dim3(256), 2 * e->T * sizeof(float), st, pa);
+    pa.emb_blocks = e->T + 1;
+    const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
+    hipLaunchKernelGGL(k_prep_train, dim3(pa.emb_blocks + main_blocks), dim3(256), 2 * e->T * sizeof(float), st, pa);
     HIP_TRY(e, hipGetLastError());
   }
   {
@@ -669,12 +670,11 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
 // nothing but Adam depends on them - and reduces the second bucket (slopes, hidden and output layer).
 // (Forking the upper wgrads to a second stream so that they also overlap the embedding backward on ONE GPU was
 // measured: the two cross-stream event waits cost more than the ~45 us they hide, 642 vs 627 us per step.)
-int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
-  if (!e) return SDRM_ERR_ARG;
-  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+// loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
+int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
-  e->bwd_begun = false;
   SeedArgs sa{};
   sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
@@ -692,25 +692,51 @@ int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, f
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
-  // dgrad chain: dpre[k] = gradient w.r.t. pre-activation k (kept for the deferred weight gradients)
+  // dpre[k] = gradient w.r.t. pre-activation k (kept for the weight gradients that run later)
   HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->WocT, e->LP, MP, e->LP, e->WP, dpre_buf(e, H), pre_buf(e, H), slope_ptr(e, H),
                         e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO, cfg_d));
   for (int k = H; k >= 1; --k)
     HIP_TRY(e, gemm_dgrad(e, dpre_buf(e, k), e->WP, e->WhcT, e->WP, MP, e->WP, e->WP, dpre_buf(e, k - 1), pre_buf(e, k - 1),
                           slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
-  // layer 0 (no latent dgrad: XT.grad is never read, Q7); its one-hot columns deliver dC0
+  // layer 0 (no latent dgrad: XT.grad is never read, Q7)
   HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
                                   Prof{e, PC_WGRAD_L0, fl0})));
-  // first bucket.  The flat gradient is written where the caller wants it (a DDP bucket) - no copy afterwards.
-  float* gout = grad ? grad : e->g;
-  e->grad_src = gout;
+  e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
+  e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+  return SDRM_OK;
+}
+
+// weight gradients of the output and hidden layers: two thirds of the wgrad flops, only Adam waits for them
+int backward_upper_wgrads(sdrm_engine* e, hipStream_t st) {
+  const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
+  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
+  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
+                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
+  for (int k = H; k >= 1; --k)
+    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
+                                     e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
+                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
+  return SDRM_OK;
+}
+
+enum { BUCKET_FIRST = 1, BUCKET_SECOND = 2, BUCKET_BOTH = 3 };
+
+// slab reduction into the flat gradient (written where the caller wants it, e.g. a DDP bucket - no copy afterwards)
+int backward_finalize(sdrm_engine* e, float* gout, int which, hipStream_t st) {
   JobTable tab;
-  build_jobs(e, tab, S0, SH, SO, dgrad_blocks, gout);
-  JobTable lo{};
-  for (int j = 0; j < tab.n; ++j)
-    if (!(tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P)) lo.j[lo.n++] = tab.j[j];
-  hipLaunchKernelGGL(k_grad_finalize, dim3(512, lo.n), dim3(256), 0, st, lo);
+  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
+  JobTable sel{};
+  for (int j = 0; j < tab.n; ++j) {
+    const bool second = tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P;
+    if ((second && (which & BUCKET_SECOND)) || (!second && (which & BUCKET_FIRST))) sel.j[sel.n++] = tab.j[j];
+  }
+  hipLaunchKernelGGL(k_grad_finalize, dim3(512, sel.n), dim3(256), 0, st, sel);
   HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+// embedding backward from dC0 (needs the first bucket's finalize): gradients of emb_layer.weight / .bias
+int backward_embedding(sdrm_engine* e, float* gout, hipStream_t st) {
   EmbBwdArgs ea{};
   ea.dC0T = e->dC0; ea.TP = e->TP;
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = gout;
@@ -718,13 +744,25 @@ int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, f
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
   hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 1023) / 1024), dim3(1024), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
-  {
-    const int items = e->T * e->T + e->T;
-    hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
-    HIP_TRY(e, hipGetLastError());
-  }
-  e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
-  e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+  const int items = e->T * e->T + e->T;
+  hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+}  // namespace
+
+int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
+  hipStream_t st = (hipStream_t)stream;
+  e->bwd_begun = false;
+  float* gout = grad ? grad : e->g;
+  e->grad_src = gout;
+  int rc = backward_chain(e, sums, loss, st);
+  if (!rc) rc = backward_finalize(e, gout, BUCKET_FIRST, st);
+  if (!rc) rc = backward_embedding(e, gout, st);
+  if (rc) return rc;
   e->bwd_begun = true;
   return SDRM_OK;
 }
@@ -735,29 +773,25 @@ int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   float* gout = grad ? grad : e->g;
   if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_finish: different gradient buffer than begin");
-  const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
-  const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
-  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
-                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
-  for (int k = H; k >= 1; --k)
-    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
-                                     e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
-                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
-  JobTable tab;
-  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
-  JobTable up{};
-  for (int j = 0; j < tab.n; ++j)
-    if (tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P) up.j[up.n++] = tab.j[j];
-  hipLaunchKernelGGL(k_grad_finalize, dim3(512, up.n), dim3(256), 0, st, up);
-  HIP_TRY(e, hipGetLastError());
+  int rc = backward_upper_wgrads(e, st);
+  if (!rc) rc = backward_finalize(e, gout, BUCKET_SECOND, st);
   e->bwd_begun = false;
-  return SDRM_OK;
+  return rc;
 }
 
+// the whole backward in one call: same kernels, one slab reduction for both buckets
 int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
-  int rc = sdrm_train_backward_begin(e, sums, grad, loss, stream);
-  if (rc) return rc;
-  return sdrm_train_backward_finish(e, grad, stream);
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
+  hipStream_t st = (hipStream_t)stream;
+  e->bwd_begun = false;
+  float* gout = grad ? grad : e->g;
+  e->grad_src = gout;
+  int rc = backward_chain(e, sums, loss, st);
+  if (!rc) rc = backward_upper_wgrads(e, st);
+  if (!rc) rc = backward_finalize(e, gout, BUCKET_BOTH, st);
+  if (!rc) rc = backward_embedding(e, gout, st);
+  return rc;
 }
 
 int sdrm_grad_buckets(const sdrm_engine* e, int64_t* first_off, int64_t* first_len, int64_t* second_off, int64_t* second_len) {

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): the bench line, the rocprofv3 kernel stats of the same command, the two PMC passes
+# (HBM traffic) and the GEMM tile sweep.  Everything lands under gpurun_out/prof_$TAG/; copy what is to be judged
+# into profiles/ afterwards (tools/pmc_summary.py turns the PMC passes into the per-kernel table).
+set -eo pipefail
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+echo "bench done"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof_stats.err"
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 93 --warmup 5 > /dev/null 2> "$OUT/pmc_fetch.err"
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 93 --warmup 5 > /dev/null 2> "$OUT/pmc_write.err"
+echo "write done"
+cd "$ROOT"
+python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt"
+CFGS=0,1,2,4 python3 tools/gemm_tune.py > "$OUT/gemm_tile_sweep.txt" 2>&1
+python3 bench.py --no-cpu-baseline --other-configs > "$OUT/bench_all_configs.json" 2> /dev/null
+# keep the merge small: the per-dispatch PMC CSVs are large
+find "$OUT/pmc_fetch" "$OUT/pmc_write" -name "*.csv" -size +8M -delete || true
+ls -la "$OUT"
