@@ -42,7 +42,8 @@ enum : int { LD_KCONTIG = 0, LD_MCONTIG = 1 };  // operand element (i,k) at src[
 enum : int { XF_NONE = 0, XF_PRELU = 1 };
 enum : int {
   EPI_BIAS = 0,          // C = acc + bias[n]                         (hidden pre-activations)
-  EPI_BIAS_TANH = 1,     // C = tanh(acc + bias[n])                   (eps-net output)
+  EPI_BIAS_TANH = 1,     // C = tanh(acc + bias[n])                   (eps-net output into the padded Y buffer)
+  EPI_BIAS_TANH_G = 2,   // same, bounds-checked: the output is an unpadded caller buffer (sdrm_forward)
   EPI_DPRELU = 3,        // C = acc * prelu'(aux) ; partial sum of acc*min(aux,0) (slope gradient)
   EPI_SLAB = 4,          // C = acc into split-K slab blockIdx.z ; optional column sums (bias grad)
   EPI_PLAIN = 5          // C = acc (debug)
@@ -99,7 +100,7 @@ struct GemmArgs {
   // EPI_SLAB
   size_t slab_stride; float* dbias; int dbias_stride;
   unsigned long long* stamps;   // diagnostic builds only (-DSDRM_STAMPS): 4 s_memtime stamps per block
-  // EPI_BIAS_TANH: output may be an unpadded caller buffer
+  // EPI_BIAS_TANH_G: extent of the unpadded caller buffer
   int rows_valid, cols_valid;
 };
 
@@ -159,6 +160,15 @@ __device__ __forceinline__ void store_tile(float* __restrict__ dst, const float4
       const int k = f / VPR, iq = f - k * VPR;
       *reinterpret_cast<float4*>(dst + k * LD + 4 * iq) = v;
     }
+  }
+}
+
+template <int NV>
+__device__ __forceinline__ void prelu_regs(float4 (&r)[NV], float slope) {
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    r[s].x = prelu_f(r[s].x, slope); r[s].y = prelu_f(r[s].y, slope);
+    r[s].z = prelu_f(r[s].z, slope); r[s].w = prelu_f(r[s].w, slope);
   }
 }
 
@@ -343,8 +353,12 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
             }
           }
         } else if (sl == 2 * NQ) {
-          DIAG_ST((store_tile_km<XFA, BM, LDK, BK>(Aw, xa, slopeA, tid)));
+          // the operand transform (PReLU of stored pre-activations) gets a shadow of its own: with the stores it
+          // overran one (12 VALU ops + two 13-cycle ds_write_b128 > 64 cycles)
+          if constexpr (XFA == XF_PRELU) prelu_regs<NVA>(xa, slopeA);
+          else DIAG_ST((store_tile_km<XF_NONE, BM, LDK, BK>(Aw, xa, 0.f, tid)));
         } else if (sl == 2 * NQ + 1) {
+          if constexpr (XFA == XF_PRELU) DIAG_ST((store_tile_km<XF_NONE, BM, LDK, BK>(Aw, xa, 0.f, tid)));
           DIAG_ST((store_tile_km<XFB, BN, LDK, BK>(Aw + BOFF, xb, slopeB, tid)));
         } else if (sl == 2 * NQ + 2) {
           DIAG_LD((load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid)));
@@ -416,13 +430,16 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 #pragma unroll
           for (int b = 0; b < TN; ++b) nb[b][g] = Br[boff + KG * g * LDB + MF * b];
         }
+        if (EPI == EPI_SLAB && do_dbias && next_valid) {   // bias gradient: this thread's column of the NEXT K-step's
+#pragma unroll                                            // dY^T tile, BK/G rows per shadow (wave-uniform branch)
+          for (int k = g * (BK / G); k < (g + 1) * (BK / G); ++k) dbsum += Ar[k * LDA + tid];
+        }
         if (g == G / 2) store_tile<LOADA, XFA, BM, LDA, BK>(Aw, xa, slopeA, tid);
         else if (g == G / 2 + 1) store_tile<LOADB, XFB, BN, LDB, BK>(Aw + BOFF, xb, slopeB, tid);
         else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid);
         else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (do_dbias && next_valid) col_sum(rs);
       __syncthreads();
     };
     if (nt > 0) {
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       const int col = tn0 + l31;
       const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) bias = p.bias[col];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G) bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -491,6 +508,12 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
           Cp[(size_t)row * p.ldc + col] = acc[a][b][r] + bias;
         }
       } else if (EPI == EPI_BIAS_TANH) {
+        float y[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) y[r] = tanh_fast(acc[a][b][r] + bias);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = y[r];
+      } else if (EPI == EPI_BIAS_TANH_G) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int row = rbase + rowoff(r);

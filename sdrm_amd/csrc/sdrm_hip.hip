@@ -854,7 +854,7 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
   GemmArgs a{};
   a.C = out; a.ldc = ldout; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
   a.rows_valid = n; a.cols_valid = cols_valid;
-  HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
+  HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH_G>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
                                                     Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W})));
   return SDRM_OK;
 }
