@@ -185,6 +185,14 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
+/* Equal-sparsity binarisation of sampled data on the device (reference: main.py:177-180,
+ *   threshold = np.quantile(M.flatten(), SPARSITY); M_equal_sparsity = (M >= threshold)):
+ * x [n] float32 (the flattened [users, items] matrix, 16-byte aligned), q in [0,1].  threshold (device float*, may
+ * be null) receives exactly what np.quantile (numpy 2.x, method "linear": float32 virtual index, float32 lerp
+ * between the two neighbouring order statistics) returns for a float32 array; out (device uint8[n], 4-byte
+ * aligned, may be null) receives x >= threshold.  Inputs must not contain NaN. */
+int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream);
+
 /* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);

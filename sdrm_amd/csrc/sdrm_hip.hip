@@ -13,6 +13,7 @@
 #include "../../include/sdrm_hip.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "select.h"
 #include "skinny.h"
 
 using namespace sdrm;
@@ -53,6 +54,7 @@ struct sdrm_engine {
   int *rowid_dev = nullptr;
   const float* grad_src = nullptr;   // where the last backward wrote the flat gradient (internal g or the caller's buffer)
   float *rev_dev = nullptr;          // [3][T+1] reverse-step coefficients c1, sqrt(alpha), sqrt(beta)
+  SelectState* sel = nullptr;        // radix-select workspace of sdrm_equal_sparsity
   std::vector<int> smp_nact, smp_perm;
   std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
   std::vector<float> h_beta, h_alpha, h_alphabar;
@@ -497,6 +499,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
+  HIP_TRY(e, dalloc(&e->sel, 1));
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
   HIP_TRY(e, dalloc(&e->dA, (size_t)(H + 1) * MP * e->WP));   // dpre_buf(0..H)
@@ -530,7 +533,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1088,6 +1091,51 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
                      e->cur_B, e->W, e->WP, out);
   HIP_TRY(me, hipGetLastError());
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Equal-sparsity binarisation of sampled data (main.py:177-180), csrc/select.h.
+int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream) {
+  if (!e || !x) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: null pointer");
+  if (n < 1) return fail(e, SDRM_ERR_SHAPE, "sdrm_equal_sparsity: n < 1");
+  if (!(q >= 0.0 && q <= 1.0)) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: q outside [0,1]");
+  if (((uintptr_t)x & 15u) || (out && ((uintptr_t)out & 3u)))
+    return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: x must be 16-byte and out 4-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  // np.quantile(a, q) for float32 `a` and a Python-float q (numpy 2.x: q and the virtual index take a's dtype):
+  //   virtual = float32(n-1) * float32(q); previous = floor(virtual); next = previous + 1; gamma = virtual - previous
+  // (volatile: every operation rounds to float32, no contraction)
+  volatile float q32 = (float)q;
+  volatile float nm1 = (float)(n - 1);
+  volatile float virt = nm1 * q32;
+  int64_t r0, r1;
+  float gamma;
+  if (virt >= nm1) { r0 = r1 = n - 1; gamma = 0.f; }
+  else if (virt < 0.f) { r0 = r1 = 0; gamma = 0.f; }
+  else {
+    const float prev = std::floor(virt);
+    volatile float g = virt - prev;
+    gamma = g;
+    r0 = (int64_t)prev; r1 = r0 + 1;
+    if (r0 > n - 1) r0 = n - 1;
+    if (r1 > n - 1) r1 = n - 1;
+  }
+  hipLaunchKernelGGL(k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
+  HIP_TRY(e, hipGetLastError());
+  const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
+  for (int pass = 0; pass < SEL_PASSES; ++pass) {
+    if (pass == 0) hipLaunchKernelGGL((k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    else hipLaunchKernelGGL((k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    HIP_TRY(e, hipGetLastError());
+    hipLaunchKernelGGL(k_select_pick, dim3(1), dim3(256), 0, st, e->sel, pass, gamma);
+    HIP_TRY(e, hipGetLastError());
+  }
+  if (threshold) HIP_TRY(e, hipMemcpyAsync(threshold, &e->sel->threshold, 4, hipMemcpyDeviceToDevice, st));
+  if (out) {
+    hipLaunchKernelGGL(k_binarize_ge, dim3(blocks), dim3(256), 0, st, x, n, (const float*)&e->sel->threshold, out);
+    HIP_TRY(e, hipGetLastError());
+  }
   return SDRM_OK;
 }
 

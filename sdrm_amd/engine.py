@@ -278,6 +278,16 @@ class Engine:
         self._keepalive = (z, keep)
         return x
 
+    def equal_sparsity(self, raw, sparsity, return_threshold=False):
+        """main.py:177-180 on the device: `(raw >= np.quantile(raw.flatten(), sparsity))` as a uint8 tensor of raw's shape
+        (and the float32 threshold np.quantile returns, as a 0-d device tensor, when asked)."""
+        raw = self._dev(raw, torch.float32)
+        out = torch.empty(raw.shape, dtype=torch.uint8, device=self.device)
+        thr = torch.empty((), dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_equal_sparsity(self._h, _ptr(raw), raw.numel(), float(sparsity), _ptr(out), _ptr(thr),
+                                                 _stream()), "sdrm_equal_sparsity")
+        return (out, thr) if return_threshold else out
+
     def perturb_input(self, x, t, noise):
         x, t, noise = self._dev(x, torch.float32), self._dev(t, torch.int64), self._dev(noise, torch.float32)
         out = torch.empty_like(x)

@@ -55,8 +55,12 @@ class EpochFeed:
         return batch_feed(self.data, self.batch_size, self.gen, self.device)
 
 
-def equal_sparsity(raw: np.ndarray, sparsity: float) -> np.ndarray:
-    return (raw >= np.quantile(raw.flatten(), sparsity)).astype(int)
+def equal_sparsity(raw, sparsity: float, engine) -> np.ndarray:
+    """main.py:177-180, `(raw >= np.quantile(raw.flatten(), SPARSITY)).astype(int)`, on the device
+    (`sdrm_equal_sparsity`: radix select of the two order statistics + binarise; csrc/select.h).  `raw` may be a
+    device tensor (what `sample_ddpm` returns) or a host array; the 0/1 matrix comes back as the host int array the
+    downstream recommenders take."""
+    return engine.equal_sparsity(raw, float(sparsity)).cpu().numpy().astype(int)
 
 
 def compute_mf_results(training_dataset, testing_dataset, synthetic_data, only_synthetic=True):
@@ -93,9 +97,9 @@ def run_experiment(split, hp, seed, vae_dir, verbose=False):
                              TRAIN_PARTIAL_VALID_DATA=train_partial, VALID_DATA=valid, OPTIMIZATION_OBJECTIVE="Recall@10",
                              verbose=verbose, cache_latents=hp.get("cache_latents", False))
     out = {}
-    M = ts.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], timesteps="random", n_timesteps=hp["T"]).detach().cpu().numpy()
-    F = ts.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], n_timesteps=hp["T"]).detach().cpu().numpy()
+    M = ts.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], timesteps="random", n_timesteps=hp["T"]).detach()
+    F = ts.sample_ddpm(n_users, net, vae, hp["latent"], hp["nd"], n_timesteps=hp["T"]).detach()
     V = vae.sample(n_users)
     for tag, raw in (("M", M), ("F", F), ("V", V)):
-        out[tag] = compute_mf_results(train, valid, equal_sparsity(raw, sparsity), only_synthetic=True)
+        out[tag] = compute_mf_results(train, valid, equal_sparsity(raw, sparsity, net.engine()), only_synthetic=True)
     return out

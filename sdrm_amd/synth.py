@@ -103,6 +103,21 @@ def synth_latents(n_rows: int, L: int, seed: int = 0) -> np.ndarray:
     return np.random.RandomState(seed).standard_normal((n_rows, L)).astype(np.float32)
 
 
+def synth_scores(n_users: int, n_items: int, seed: int = 0, kind: str = "normal") -> np.ndarray:
+    """Decoder-output-shaped scores [n_users, n_items] for the equal-sparsity / ranking rows:
+    "normal": N(-2, 1.5) logits; "ties": the same rounded to 1/8 (many exact duplicates, also at the threshold);
+    "narrow": all values inside one binade (stresses the first radix digit)."""
+    rs = np.random.RandomState(seed)
+    x = (rs.standard_normal((n_users, n_items)) * 1.5 - 2.0).astype(np.float32)
+    if kind == "ties":
+        x = (np.round(x * 8.0) / 8.0).astype(np.float32)
+    elif kind == "narrow":
+        x = (1.0 + 0.5 * rs.random_sample((n_users, n_items))).astype(np.float32)
+    elif kind != "normal":
+        raise ValueError(kind)
+    return x
+
+
 def synth_train_randoms(B: int, L: int, T: int, nd: float, seed: int):
     """One train step's explicit randoms: eps=nd*N(0,1) [B,L], t~U{1..T} [B] i64,
     three Bernoulli(0.5) keep-masks [3,B,L] u8 (pass order P,S,Q)."""

@@ -565,13 +565,38 @@ def fixture_e2e(ref):
     np.savez_compressed(os.path.join(HERE, "e2e_ml100k_svd.npz"), **out)
 
 
+def fixture_equal_sparsity(ref=None):
+    """main.py:177-180 verbatim on synthetic decoder outputs: threshold = np.quantile(M.flatten(), SPARSITY);
+    M_equal_sparsity = (M >= threshold).astype(int).  The arithmetic is numpy's (this container: numpy 2.2.6)."""
+    out = {}
+    cases = [("normal", 37, 101, 0.937), ("ties", 64, 250, 0.9), ("narrow", 50, 333, 0.0634), ("normal", 1, 1, 0.5),
+             ("normal", 3, 5, 0.0), ("normal", 3, 5, 1.0), ("ties", 40, 100, 0.5), ("normal", 211, 997, 0.99)]
+    out["n_cases"] = np.asarray(len(cases))
+    for i, (kind, users, items, sparsity) in enumerate(cases):
+        M = synth.synth_scores(users, items, seed=100 + i, kind=kind)
+        threshold = np.quantile(M.flatten(), sparsity)
+        eq = (M >= threshold).astype(int)
+        out[f"c{i}_kind"] = np.asarray(kind)
+        out[f"c{i}_shape"] = np.asarray([users, items, 100 + i])
+        out[f"c{i}_sparsity"] = np.asarray(sparsity)
+        out[f"c{i}_threshold"] = np.asarray(threshold)
+        out[f"c{i}_bits"] = np.packbits(eq.astype(np.uint8).ravel())
+        out[f"c{i}_ones"] = np.asarray(int(eq.sum()))
+    np.savez_compressed(os.path.join(HERE, "equal_sparsity.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host"]
+    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity"]
+    if which == ["equal_sparsity"]:     # numpy only: no need to import the reference
+        fixture_equal_sparsity()
+        print("wrote equal_sparsity")
+        return
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
              "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
-             "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e}
+             "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e,
+             "equal_sparsity": fixture_equal_sparsity}
     for w in which:
         table[w](ref)
         print("wrote", w)
