@@ -193,6 +193,20 @@ const char* sdrm_build_info(void);
  * aligned, may be null) receives x >= threshold.  Inputs must not contain NaN. */
 int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream);
 
+/* Recall@k and NDCG@k of a score matrix against held-out interactions (reference: utilities.py:116-171,
+ * mask_training_examples + recall_at_k_batch + NDCG_binary_at_k_batch, as svd_benchmark.py:58-66 chains them).
+ * scores [U, I] float32 row-major; held_* / train_* are CSR index arrays over the same U rows (int64 indptr [U+1],
+ * int32 column indices; every stored entry counts as an interaction); train_* may both be null (no masking,
+ * otherwise those items score -inf).  ks_host: nk <= 8 cut-offs (HOST array, each 1 <= k <= min(128, I)).
+ * tp [kmax] = 1/log2(r+2) and idcg [kmax+1] = sum(tp[:m]) are float64 DEVICE tables computed by the caller with numpy
+ * so that the constants are the reference's own.  recall, ndcg: [nk, U] float64 (nan where a user has nothing held
+ * out, like the reference's 0/0).  Ties in the scores rank towards the lower item index (the reference's
+ * argpartition leaves them unspecified). */
+int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const int64_t* held_indptr,
+                      const int32_t* held_indices, const int64_t* train_indptr, const int32_t* train_indices,
+                      const int32_t* ks_host, int nk, const double* tp, const double* idcg, double* recall, double* ndcg,
+                      void* stream);
+
 /* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sdrm_profile_get": (c_int, [c_void_p, c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "sdrm_build_info": (C.c_char_p, []),
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),
+    "sdrm_rank_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdrm_debug_set_tile": (c_int, [c_int]),
     "sdrm_debug_set_chains": (c_int, [c_int]),
     "sdrm_debug_set_skinny": (c_int, [c_int]),

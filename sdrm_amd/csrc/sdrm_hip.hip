@@ -13,6 +13,7 @@
 #include "../../include/sdrm_hip.h"
 #include "elementwise.h"
 #include "gemm.h"
+#include "rank.h"
 #include "select.h"
 #include "skinny.h"
 
@@ -1136,6 +1137,38 @@ int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uin
     hipLaunchKernelGGL(k_binarize_ge, dim3(blocks), dim3(256), 0, st, x, n, (const float*)&e->sel->threshold, out);
     HIP_TRY(e, hipGetLastError());
   }
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Recall@k / NDCG@k against held-out interactions (utilities.py:116-171), csrc/rank.h.
+int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const int64_t* held_indptr,
+                      const int32_t* held_indices, const int64_t* train_indptr, const int32_t* train_indices,
+                      const int32_t* ks_host, int nk, const double* tp, const double* idcg, double* recall, double* ndcg,
+                      void* stream) {
+  if (!e || !scores || !held_indptr || !held_indices || !ks_host || !tp || !idcg || !recall || !ndcg)
+    return fail(e, SDRM_ERR_ARG, "sdrm_rank_metrics: null pointer");
+  if ((train_indptr == nullptr) != (train_indices == nullptr))
+    return fail(e, SDRM_ERR_ARG, "sdrm_rank_metrics: train_indptr and train_indices go together");
+  if (U < 1 || I < 1 || I > 36864) return fail(e, SDRM_ERR_SHAPE, "sdrm_rank_metrics: U < 1 or I outside [1, 36864]");
+  if (nk < 1 || nk > RANK_MAX_NK) return fail(e, SDRM_ERR_ARG, "sdrm_rank_metrics: nk outside [1, 8]");
+  RankArgs a{};
+  a.scores = scores; a.U = U; a.I = I;
+  a.held_indptr = held_indptr; a.held_indices = held_indices;
+  a.train_indptr = train_indptr; a.train_indices = train_indices;
+  a.nk = nk; a.kmax = 0;
+  for (int q = 0; q < nk; ++q) {
+    if (ks_host[q] < 1 || ks_host[q] > RANK_MAX_K || ks_host[q] > I)
+      return fail(e, SDRM_ERR_ARG, "sdrm_rank_metrics: k outside [1, min(128, I)]");
+    a.ks[q] = ks_host[q];
+    if (ks_host[q] > a.kmax) a.kmax = ks_host[q];
+  }
+  a.tp = tp; a.idcg = idcg; a.recall = recall; a.ndcg = ndcg;
+  const size_t lds = (size_t)I * sizeof(float);
+  if (lds > 48 * 1024)
+    HIP_TRY(e, hipFuncSetAttribute((const void*)k_rank_metrics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_rank_metrics, dim3(U), dim3(256), lds, (hipStream_t)stream, a);
+  HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
 

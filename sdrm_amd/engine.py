@@ -288,6 +288,34 @@ class Engine:
                                                  _stream()), "sdrm_equal_sparsity")
         return (out, thr) if return_threshold else out
 
+    def rank_metrics(self, scores, heldout, train=None, ks=(1, 3, 5, 10, 20, 50)):
+        """utilities.py:116-171 on the device: (recall[nk,U], ndcg[nk,U]) float64 device tensors for a score matrix
+        [U, I] (device or host) against the held-out CSR matrix, with the items of the `train` CSR matrix masked out
+        (-inf).  `heldout` / `train` are scipy.sparse matrices (or anything with tocsr())."""
+        scores = self._dev(scores, torch.float32)
+        U, I = scores.shape
+        ks = np.asarray(ks, dtype=np.int32)
+        kmax = int(ks.max())
+        tp = 1.0 / np.log2(np.arange(2, kmax + 2))                                   # utilities.py:145
+        idcg = np.asarray([tp[:m].sum() for m in range(kmax + 1)], dtype=np.float64)   # utilities.py:149-150
+
+        def csr(m):
+            m = m.tocsr()
+            if m.shape != (U, I):
+                raise SdrmError(f"rank_metrics: sparse matrix shape {m.shape} != scores shape {(U, I)}")
+            return (torch.from_numpy(m.indptr.astype(np.int64)).to(self.device),
+                    torch.from_numpy(m.indices.astype(np.int32)).to(self.device))
+        hp, hi = csr(heldout)
+        tr = csr(train) if train is not None else (None, None)
+        tp_d, idcg_d = torch.from_numpy(tp).to(self.device), torch.from_numpy(idcg).to(self.device)
+        recall = torch.empty(len(ks), U, dtype=torch.float64, device=self.device)
+        ndcg = torch.empty(len(ks), U, dtype=torch.float64, device=self.device)
+        self._check(self.lib.sdrm_rank_metrics(self._h, _ptr(scores), U, I, _ptr(hp), _ptr(hi), _ptr(tr[0]), _ptr(tr[1]),
+                                               ks.ctypes.data_as(C.c_void_p), len(ks), _ptr(tp_d), _ptr(idcg_d),
+                                               _ptr(recall), _ptr(ndcg), _stream()), "sdrm_rank_metrics")
+        self._keepalive = (scores, hp, hi, tr, tp_d, idcg_d)
+        return recall, ndcg
+
     def perturb_input(self, x, t, noise):
         x, t, noise = self._dev(x, torch.float32), self._dev(t, torch.int64), self._dev(noise, torch.float32)
         out = torch.empty_like(x)

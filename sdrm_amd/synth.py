@@ -118,6 +118,24 @@ def synth_scores(n_users: int, n_items: int, seed: int = 0, kind: str = "normal"
     return x
 
 
+def synth_interactions(n_users: int, n_items: int, seed: int = 0, p_train: float = 0.05, p_held: float = 0.02):
+    """(train, heldout) disjoint binary interaction matrices as scipy CSR [n_users, n_items]: every third user of the
+    first nine has nothing held out / very many held out / nothing seen, to exercise the metric edge cases."""
+    from scipy.sparse import csr_matrix
+    rs = np.random.RandomState(seed)
+    u = rs.random_sample((n_users, n_items))
+    train = u < p_train
+    held = (u >= p_train) & (u < p_train + p_held)
+    for r in range(min(n_users, 9)):
+        if r % 3 == 0:
+            held[r, :] = False
+        elif r % 3 == 1:
+            held[r, :] = (u[r] >= p_train) & (u[r] < p_train + 0.5)
+        else:
+            train[r, :] = False
+    return csr_matrix(train.astype(np.float64)), csr_matrix(held.astype(np.float64))
+
+
 def synth_train_randoms(B: int, L: int, T: int, nd: float, seed: int):
     """One train step's explicit randoms: eps=nd*N(0,1) [B,L], t~U{1..T} [B] i64,
     three Bernoulli(0.5) keep-masks [3,B,L] u8 (pass order P,S,Q)."""

@@ -565,6 +565,32 @@ def fixture_e2e(ref):
     np.savez_compressed(os.path.join(HERE, "e2e_ml100k_svd.npz"), **out)
 
 
+def fixture_rank_metrics(ref):
+    """utilities.py:116-171 as svd_benchmark.py:58-66 chains them: mask_training_examples, then recall_at_k_batch and
+    NDCG_binary_at_k_batch for k = 1,3,5,10,20,50 - run by the reference's own functions on synthetic scores (rows
+    checked to be tie-free, since bn.argpartition leaves ties unspecified) and synthetic interactions."""
+    import utilities as refutil
+    out = {}
+    cases = [(48, 300, 11), (20, 64, 12), (9, 2000, 13)]
+    ks = [1, 3, 5, 10, 20, 50]
+    out["ks"] = np.asarray(ks)
+    out["n_cases"] = np.asarray(len(cases))
+    for ci, (users, items, seed) in enumerate(cases):
+        scores = synth.synth_scores(users, items, seed=seed)
+        assert all(len(np.unique(r)) == items for r in scores), "tie in a score row: pick another seed"
+        train, held = synth.synth_interactions(users, items, seed=seed)
+        masked = refutil.mask_training_examples(train, scores.copy())
+        rec, ndcg = [], []
+        with np.errstate(all="ignore"):
+            for k in ks:
+                rec.append(refutil.recall_at_k_batch(masked.copy(), held, k=k))
+                ndcg.append(refutil.NDCG_binary_at_k_batch(masked.copy(), held, k=k))
+        out[f"c{ci}_shape"] = np.asarray([users, items, seed])
+        out[f"c{ci}_recall"] = np.asarray(rec, dtype=np.float64)
+        out[f"c{ci}_ndcg"] = np.asarray(ndcg, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "rank_metrics.npz"), **out)
+
+
 def fixture_equal_sparsity(ref=None):
     """main.py:177-180 verbatim on synthetic decoder outputs: threshold = np.quantile(M.flatten(), SPARSITY);
     M_equal_sparsity = (M >= threshold).astype(int).  The arithmetic is numpy's (this container: numpy 2.2.6)."""
@@ -588,7 +614,7 @@ def fixture_equal_sparsity(ref=None):
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity"]
+    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity", "rank_metrics"]
     if which == ["equal_sparsity"]:     # numpy only: no need to import the reference
         fixture_equal_sparsity()
         print("wrote equal_sparsity")
@@ -596,7 +622,7 @@ def main():
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
              "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
              "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e,
-             "equal_sparsity": fixture_equal_sparsity}
+             "equal_sparsity": fixture_equal_sparsity, "rank_metrics": fixture_rank_metrics}
     for w in which:
         table[w](ref)
         print("wrote", w)
