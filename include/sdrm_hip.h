@@ -185,6 +185,14 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
+/* Sparse batch feed (reference: dataloaders.py:46-79 builds a COO tensor per batch on the host, train_SDRM.py:323
+ * densifies it before vae.encode).  The CSR matrix of the whole feed [n_rows, n_items] stays on the device (int64
+ * indptr, int32 column indices, float32 data or null for all-ones); out [b, n_items] float32 receives the dense rows
+ * rows[0..b) (device int64 array; the caller's epoch permutation) or, when rows is null, rows row0 .. row0+b-1.
+ * Row ids and column indices are not range-checked. */
+int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data,
+                           const int64_t* rows, int64_t row0, int b, int n_items, float* out, void* stream);
+
 /* Equal-sparsity binarisation of sampled data on the device (reference: main.py:177-180,
  *   threshold = np.quantile(M.flatten(), SPARSITY); M_equal_sparsity = (M >= threshold)):
  * x [n] float32 (the flattened [users, items] matrix, 16-byte aligned), q in [0,1].  threshold (device float*, may

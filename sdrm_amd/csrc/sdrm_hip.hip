@@ -12,6 +12,7 @@
 
 #include "../../include/sdrm_hip.h"
 #include "elementwise.h"
+#include "feed.h"
 #include "gemm.h"
 #include "rank.h"
 #include "select.h"
@@ -1092,6 +1093,19 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
                      e->cur_B, e->W, e->WP, out);
   HIP_TRY(me, hipGetLastError());
+  return SDRM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse batch feed (dataloaders.py:46-79, train_SDRM.py:323), csrc/feed.h.
+int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data,
+                           const int64_t* rows, int64_t row0, int b, int n_items, float* out, void* stream) {
+  if (!e || !indptr || !indices || !out) return fail(e, SDRM_ERR_ARG, "sdrm_csr_rows_to_dense: null pointer");
+  if (b < 1 || n_items < 1 || row0 < 0) return fail(e, SDRM_ERR_SHAPE, "sdrm_csr_rows_to_dense: b < 1, n_items < 1 or row0 < 0");
+  FeedArgs a{};
+  a.indptr = indptr; a.indices = indices; a.data = data; a.rows = rows; a.row0 = row0; a.b = b; a.n_items = n_items; a.out = out;
+  hipLaunchKernelGGL(k_csr_rows_to_dense, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
+  HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
 

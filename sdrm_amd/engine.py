@@ -288,6 +288,31 @@ class Engine:
                                                  _stream()), "sdrm_equal_sparsity")
         return (out, thr) if return_threshold else out
 
+    def csr_to_device(self, m):
+        """(indptr i64, indices i32, data f32 | None for an all-ones matrix, shape) of a scipy sparse matrix, on the device."""
+        m = m.tocsr().copy()
+        m.sum_duplicates()
+        m.sort_indices()
+        data = None if np.all(m.data == 1) else torch.from_numpy(m.data.astype(np.float32)).to(self.device)
+        return (torch.from_numpy(m.indptr.astype(np.int64)).to(self.device),
+                torch.from_numpy(m.indices.astype(np.int32)).to(self.device), data, m.shape)
+
+    def csr_rows_to_dense(self, csr_dev, rows=None, row0=0, b=None):
+        """dataloaders.py:46-79 + `.to_dense()` (train_SDRM.py:323) on the device: dense float32 [b, n_items] of the rows
+        `rows` (int64 tensor, e.g. a slice of the epoch permutation) or row0 .. row0+b-1 of a `csr_to_device` matrix."""
+        indptr, indices, data, (n_rows, n_items) = csr_dev
+        if rows is not None:
+            rows = self._dev(rows, torch.int64)
+            b = rows.numel()
+            if b and (int(rows.min()) < 0 or int(rows.max()) >= n_rows):
+                raise SdrmError("csr_rows_to_dense: row id outside the matrix")
+        elif b is None or row0 < 0 or row0 + b > n_rows:
+            raise SdrmError("csr_rows_to_dense: row range outside the matrix")
+        out = torch.empty(b, n_items, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_csr_rows_to_dense(self._h, _ptr(indptr), _ptr(indices), _ptr(data), _ptr(rows), int(row0), int(b),
+                                                    int(n_items), _ptr(out), _stream()), "sdrm_csr_rows_to_dense")
+        return out
+
     def rank_metrics(self, scores, heldout, train=None, ks=(1, 3, 5, 10, 20, 50)):
         """utilities.py:116-171 on the device: (recall[nk,U], ndcg[nk,U]) float64 device tensors for a score matrix
         [U, I] (device or host) against the held-out CSR matrix, with the items of the `train` CSR matrix masked out
@@ -322,3 +347,16 @@ class Engine:
         self._check(self.lib.sdrm_perturb_input(self._h, _ptr(x), _ptr(t), _ptr(noise), x.shape[0], _ptr(out), _stream()),
                     "sdrm_perturb_input")
         return out
+
+
+_UTILITY = {}
+
+
+def utility_engine(device=None) -> Engine:
+    """A small cached engine for the handle-independent device ops (equal_sparsity, rank_metrics, csr_rows_to_dense):
+    the C ABI hangs error strings and the select workspace on a handle, nothing of the eps-net is used."""
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    eng = _UTILITY.get(idx)
+    if eng is None or not eng._h:
+        eng = _UTILITY[idx] = Engine(8, 8, 4, 0, 16, device=idx)
+    return eng

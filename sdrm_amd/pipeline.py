@@ -55,6 +55,26 @@ class EpochFeed:
         return batch_feed(self.data, self.batch_size, self.gen, self.device)
 
 
+class DeviceFeed:
+    """The same epoch feed with the CSR matrix resident on the device: every `iter()` draws the
+    permutation the reference's RandomSampler would (torch.randperm on the carried CPU generator) and each batch is
+    densified in HBM by `sdrm_csr_rows_to_dense` - what `x.to_dense()` (train_SDRM.py:323) would have produced from the
+    host-built COO tensor.  Yields dense tensors (`.to_dense()` of a dense tensor is the tensor itself)."""
+
+    def __init__(self, data, batch_size, engine, seed=None):
+        self.engine, self.batch_size, self.n_rows = engine, batch_size, data.shape[0]
+        self.csr = engine.csr_to_device(data)
+        self.gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self.gen.manual_seed(seed)
+
+    def __iter__(self):
+        perm = torch.randperm(self.n_rows, generator=self.gen).to(self.engine.device)
+        for lo in range(0, self.n_rows, self.batch_size):
+            x = self.engine.csr_rows_to_dense(self.csr, rows=perm[lo:lo + self.batch_size])
+            yield x, x
+
+
 def equal_sparsity(raw, sparsity: float, engine) -> np.ndarray:
     """main.py:177-180, `(raw >= np.quantile(raw.flatten(), SPARSITY)).astype(int)`, on the device
     (`sdrm_equal_sparsity`: radix select of the two order statistics + binarise; csrc/select.h).  `raw` may be a
@@ -90,7 +110,8 @@ def run_experiment(split, hp, seed, vae_dir, verbose=False):
     sparsity = 1 - train.nnz / (n_users * n_items)
     torch.manual_seed(seed)
     np.random.seed(seed)
-    dl = EpochFeed(train_partial, hp["batch"], device="cuda")
+    from .engine import utility_engine
+    dl = DeviceFeed(train_partial, hp["batch"], utility_engine())      # CSR resident in HBM, batches densified there
     net, vae = ts.train_SDRM(dl, N_ITEMS=n_items, VAE_HIDDEN=hp["vae_hidden"], VAE_LATENT=hp["latent"], VAE_BATCH_SIZE=hp["vae_batch"],
                              VAE_LR=hp["vae_lr"], DIFF_LATENT=hp["latent"], N_HIDDEN_MLP_LAYERS=hp["H"], DIFF_LR=hp["lr"],
                              DIFF_TRAINING_EPOCHS=hp["epochs"], TIMESTEPS=hp["T"], noise_divider=hp["nd"], VAE_DIR_PATH=vae_dir,

@@ -33,7 +33,7 @@ from torch.nn import functional as F
 
 from . import metrics as utilities
 from . import synth
-from .engine import Engine, SdrmError
+from .engine import Engine, SdrmError, utility_engine
 
 warnings.filterwarnings("ignore")
 
@@ -239,7 +239,6 @@ def train_variational_autoencoder(model, train_data, test_data, epochs, batch_si
     dev = next(model.parameters()).device
     anneal_cap, anneal_count = 0.2, 0.0
     best_metric, best_epoch, stale = -np.inf, 0, 0
-    metric_engine = None
     optimizer = torch.optim.Adam(model.parameters(), lr=lr)
     k = int(early_stop_metric.split("@")[1])
     start = time.time()
@@ -271,9 +270,7 @@ def train_variational_autoencoder(model, train_data, test_data, epochs, batch_si
                 pred, _ = model(torch.tensor(X.toarray(), dtype=torch.float32, device=dev))
                 if dev.type == "cuda":
                     # utilities.py:116-171 on the device (sdrm_rank_metrics): the [500, N_ITEMS] scores stay in HBM
-                    if metric_engine is None:
-                        metric_engine = Engine(8, 8, 4, 0, 16, device=dev.index)
-                    rec, ndcg = metric_engine.rank_metrics(pred, valid_test[lo:hi], train=X, ks=(k,))
+                    rec, ndcg = utility_engine(dev).rank_metrics(pred, valid_test[lo:hi], train=X, ks=(k,))
                     scores.append((rec if "Recall" in early_stop_metric else ndcg)[0].cpu().numpy())
                 else:
                     pred = utilities.mask_training_examples(X, pred.cpu().numpy())
@@ -292,8 +289,6 @@ def train_variational_autoencoder(model, train_data, test_data, epochs, batch_si
                     print(f"MultiVAE++ training complete. Early stopping at epoch {epoch}, "
                           f"Training took {np.round((time.time() - start) / 60, 2)} minutes")
                 break
-    if metric_engine is not None:
-        metric_engine.close()
     resume(model, f"epoch-{best_epoch}.pth", VAE_DIR_PATH)
     model.model_is_trained = True
     model.is_training = 0
