@@ -15,17 +15,21 @@ for N in [int(v) for v in os.environ.get("SHARDS", "1,2,4,8").split(",")]:
     sums = torch.zeros(8, dtype=torch.float64, device="cuda"); grad = torch.zeros(e.P, device="cuda")
     def train():
         e.train_forward(x0, seed=1, step=3, sums=sums); e.train_backward(sums=sums, grad=grad); e.adam_step(1e-5, grad=grad)
-    def timeit(fn, reps):
+    cpu_us = {}
+    def timeit(fn, reps, tag=None):
         for _ in range(5): fn()
         torch.cuda.synchronize(); t = time.perf_counter()
         for _ in range(reps): fn()
-        torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e6
-    tt = timeit(train, 100)
+        t_enq = time.perf_counter() - t          # host time to enqueue (the GPU may still be busy)
+        torch.cuda.synchronize()
+        if tag: cpu_us[tag] = t_enq / reps * 1e6
+        return (time.perf_counter() - t) / reps * 1e6
+    tt = timeit(train, 100, 'train')
     e.sample_begin(n, seed=2, call_id=1)
     def samp():
         if e.sample_steps(1) == 0:
             e.sample_end(); e.sample_begin(n, seed=2, call_id=1)
-    ts = timeit(samp, 156)
+    ts = timeit(samp, 156, 'sample')
     print(f"N={N}: rows/rank {B:5d} train step {tt:7.1f} us   n/rank {n:5d} sample step {ts:6.1f} us   "
-          f"cycle(15:78) {15*tt+78*ts:8.0f} us  (compute only, no all-reduce)", flush=True)
+          f"cycle(15:78) {15*tt+78*ts:8.0f} us  (compute only, no all-reduce); host enqueue {cpu_us['train']:.0f} / {cpu_us['sample']:.0f} us per step", flush=True)
     e.close()
