@@ -64,9 +64,11 @@ constexpr int NTHREADS = 256;
 // v_mfma_f32_16x16x4_f32 (4 VGPRs).  Same flop rate; the 16-wide form lets a 32x32 block tile be split over four
 // waves, which is what a launch with few rows needs: it cannot fill the chip with 64x64 tiles, and a lone block's
 // time is its per-wave chain of dependent MFMAs (K/2 x 64 cycles for a 32x32 tile, K/4 x 32 for a 16x16 one).
-template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4, int BK_ = 16, int MF_ = 32>
+// PF = global-prefetch register sets of the NT loop: 2 (loads requested four K-steps ahead of their MFMAs) or 1 (three
+// ahead; what a 32-deep K-step can afford inside 128 VGPRs, and its step is twice as long anyway).
+template <int BM_, int BN_, int WM_, int WN_, int MINW_ = 4, int BK_ = 16, int MF_ = 32, int PF_ = 2>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, MF = MF_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, BK = BK_, MF = MF_, PF = PF_;
   static constexpr int MINW = MINW_;   // waves per SIMD the register allocator must leave room for
   static constexpr int TM = BM_ / WM_ / MF_, TN = BN_ / WN_ / MF_;   // MFMA tiles per wave
   static constexpr int PADMAX = (MF_ == 32) ? 4 : 16;
@@ -370,12 +372,20 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       DIAG_BAR();
     };
     if (nt > 0) {
-      ld(ra0, rb0, 0);
-      ld(ra1, rb1, 1);
-      st(ra0, rb0, 0);
-      ld(ra0, rb0, 2);
-      st(ra1, rb1, 1);
-      ld(ra1, rb1, 3);
+      if constexpr (Cfg::PF == 2) {
+        ld(ra0, rb0, 0);
+        ld(ra1, rb1, 1);
+        st(ra0, rb0, 0);
+        ld(ra0, rb0, 2);
+        st(ra1, rb1, 1);
+        ld(ra1, rb1, 3);
+      } else {
+        ld(ra0, rb0, 0);
+        st(ra0, rb0, 0);
+        ld(ra0, rb0, 1);
+        st(ra0, rb0, 1);
+        ld(ra0, rb0, 2);
+      }
       __syncthreads();
 #ifdef SDRM_STAMPS
       if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
@@ -385,11 +395,17 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       // step i multiplies out of fragment set i%2, reads step i+1's fragments from stage (i+1)%2, stores step i+2
       // (prefetch set i%2) into stage i%2 and requests step i+4 into the same set.  (Four prefetch sets, i.e. loads
       // requested four steps ahead, were measured: 3 % off a lone work-group's loop, 2 % slower on full launches.)
+      // PF == 1: the single set holds step i+2 when step i stores it and is refilled with step i+3.
       auto run = [&](auto tag) {
         int i = 0;
         for (; i + 1 < nt; i += 2) {
-          kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 4);
-          kstep(tag, fa1, fb1, fa0, fb0, 0, ra1, rb1, 1, i + 5);
+          if constexpr (Cfg::PF == 2) {
+            kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 4);
+            kstep(tag, fa1, fb1, fa0, fb0, 0, ra1, rb1, 1, i + 5);
+          } else {
+            kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 3);
+            kstep(tag, fa1, fb1, fa0, fb0, 0, ra0, rb0, 1, i + 4);
+          }
         }
         if (i < nt) kstep(tag, fa0, fb0, fa1, fb1, 1, ra0, rb0, 0, i + 4);   // odd count (its pieces are harmless)
       };

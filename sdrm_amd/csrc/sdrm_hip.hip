@@ -141,7 +141,7 @@ struct Prof { sdrm_engine* e; int cls; double flops; };
 // for 128x128x16): K is only ~350 deep, so a block is mostly prologue/epilogue and per-K-step barrier
 // latency, and what hides that is many co-resident blocks (17 KB of LDS -> 9 per CU), not a big tile.
 typedef TileCfg<64, 64, 2, 2, 4, 16> Cfg0;     //  64x 64x16  (default)
-typedef TileCfg<64, 64, 2, 2, 2, 32> Cfg1;     //  64x 64x32
+typedef TileCfg<64, 64, 2, 2, 4, 32, 32, 1> Cfg1;  //  64x 64x32, one prefetch set
 typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
 typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
 typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32: launches too small to fill the chip
