@@ -203,6 +203,23 @@ def pmc_traffic(kernel_class: str):
     return None, None
 
 
+def pmc_mfma_busy(kernel_class: str):
+    """Matrix-pipe busy cycles per SIMD and launch of the dominant kernel from the committed SQ counter pass
+    (profiles/*pmc_sq.json, made by tools/pmc_sq.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...` of this command)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_sq.json")))
+    m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
+    if not files or not m:
+        return None
+    needle = ", " + ", ".join(m.groups()) + ">("
+    for name, rows in json.load(open(files[-1])).get("kernels", {}).items():
+        if needle in name and rows:
+            rows = sorted(rows, key=lambda r: r["grid_size"])
+            return (rows[0] if kernel_class.startswith("sample") else rows[-1])["mfma_busy_per_simd_cycles"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,6 +318,9 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": src,
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "launches": launches,
+                    "mfma_busy_cycles_per_simd": pmc_mfma_busy(name),
+                    "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs per launch (PMC pass); divide by avg_launch_us x "
+                                      "shader clock (~2.1 GHz in kernels this short, tools/mfma_probe.hip) for the pipe utilisation",
                     "algorithmic_flops_per_launch": flops / launches,
                     "all_kernels": {k: {"ms": round(v[0], 3), "launches": v[1],
                                         "tflops": round(v[2] / (v[0] * 1e-3) / 1e12, 2)} for k, v in prof.items()}}

@@ -17,10 +17,13 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$
 echo "fetch done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 93 --warmup 5 > /dev/null 2> "$OUT/pmc_write.err"
 echo "write done"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq" -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 93 --warmup 5 > /dev/null 2> "$OUT/pmc_sq.err"
+echo "sq done"
 cd "$ROOT"
+python3 tools/pmc_sq.py "$OUT/pmc_sq" "$OUT/pmc_sq.json" > "$OUT/pmc_sq.txt"
 python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt"
 CFGS=0,1,2,4 python3 tools/gemm_tune.py > "$OUT/gemm_tile_sweep.txt" 2>&1
 python3 bench.py --no-cpu-baseline --other-configs > "$OUT/bench_all_configs.json" 2> /dev/null
 # keep the merge small: the per-dispatch PMC CSVs are large
-find "$OUT/pmc_fetch" "$OUT/pmc_write" -name "*.csv" -size +8M -delete || true
+find "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" -name "*.csv" -size +8M -delete || true
 ls -la "$OUT"
