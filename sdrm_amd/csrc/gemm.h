@@ -46,7 +46,9 @@ enum : int {
   EPI_BIAS_TANH_G = 2,   // same, bounds-checked: the output is an unpadded caller buffer (sdrm_forward)
   EPI_DPRELU = 3,        // C = acc * prelu'(aux) ; partial sum of acc*min(aux,0) (slope gradient)
   EPI_SLAB = 4,          // C = acc into split-K slab blockIdx.z ; optional column sums (bias grad)
-  EPI_PLAIN = 5          // C = acc (debug)
+  EPI_PLAIN = 5,         // C = acc (debug)
+  EPI_TANH_REV = 6       // eps_hat = tanh(acc + bias) feeds the DDPM reverse update of the sampler state in place
+                         // (k_reverse_update fused: on-device Philox, full-resolution sampling)
 };
 
 constexpr int NTHREADS = 256;
@@ -104,6 +106,11 @@ struct GemmArgs {
   unsigned long long* stamps;   // diagnostic builds only (-DSDRM_STAMPS): 4 s_memtime stamps per block
   // EPI_BIAS_TANH_G: extent of the unpadded caller buffer
   int rows_valid, cols_valid;
+  // EPI_TANH_REV: sampler state X [rows][ldx] (updated in place), next step's dropped-out input U [rows][ldx];
+  // rows of this launch are slots rev_s0 .. of the sampler, global row (Philox key) = rev_row0 + slot
+  float* revX; float* revU; int rev_ldx, rev_s0, rev_n, rev_L, rev_step;
+  float rev_c1, rev_sqrt_alpha, rev_sqrt_beta, rev_nd;
+  uint32_t rev_seed_lo, rev_seed_hi, rev_call_id; int64_t rev_row0;
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
       const int col = tn0 + l31;
       const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G) bias = p.bias[col];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G || EPI == EPI_TANH_REV) bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -529,6 +536,48 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
         for (int r = 0; r < NR; ++r) y[r] = tanh_fast(acc[a][b][r] + bias);
 #pragma unroll
         for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = y[r];
+      } else if (EPI == EPI_TANH_REV) {
+        // x <- (x - eps_hat*c1)/sqrt(alpha_i) + sqrt(beta_i)*z ; U_next = keep ? 2x : 0   (train_SDRM.py:20-25 + :100),
+        // the arithmetic of k_reverse_update.  One Philox call serves a column PAIR (two normals, two keep bits): the
+        // even-column lane draws for the first half of its rows, its odd-column neighbour for the second half, and
+        // they swap through the wave (lane ^ 1) - one call per pair, as in the stand-alone kernel.
+        constexpr int HALF = NR / 2;
+        const bool odd = col & 1;
+        const bool noise = p.rev_step > 1;
+        float zlo[HALF], zhi[HALF];
+        uint32_t blo[HALF], bhi[HALF];
+#pragma unroll
+        for (int h = 0; h < HALF; ++h) {
+          float n0 = 0.f, n1 = 0.f;
+          uint32_t bits = 0u;
+          if (noise) {
+            const int slot = p.rev_s0 + rbase + rowoff(odd ? HALF + h : h);
+            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 1),
+                                       PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);
+            box_muller(w.x, w.y, n0, n1);
+            n0 *= p.rev_nd; n1 *= p.rev_nd;
+            bits = w.z;
+          }
+          const float mine = odd ? n1 : n0, theirs = odd ? n0 : n1;     // my column's normal / my neighbour's
+          const float got = __shfl_xor(theirs, 1, 64);                   // the neighbour drew my normal for ITS rows
+          const uint32_t gotb = (uint32_t)__shfl_xor((int)bits, 1, 64);
+          zlo[h] = odd ? got : mine;  blo[h] = odd ? gotb : bits;        // rows h         (drawn by the even lane)
+          zhi[h] = odd ? mine : got;  bhi[h] = odd ? bits : gotb;        // rows HALF + h  (drawn by the odd lane)
+        }
+        const int sh = odd ? 8 : 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
+          const float z = r < HALF ? zlo[r % HALF] : zhi[r % HALF];
+          const bool kp = ((r < HALF ? blo[r % HALF] : bhi[r % HALF]) >> sh) & 1u;
+          if (row + p.rev_s0 < p.rev_n) {
+            const size_t xi = (size_t)(p.rev_s0 + row) * p.rev_ldx + col;
+            const float e = tanh_fast(acc[a][b][r] + bias);
+            const float xn = (col < p.rev_L) ? (p.revX[xi] - e * p.rev_c1) / p.rev_sqrt_alpha + p.rev_sqrt_beta * z : 0.f;
+            p.revX[xi] = xn;
+            if (noise) p.revU[xi] = kp ? 2.f * xn : 0.f;
+          }
+        }
       } else if (EPI == EPI_BIAS_TANH_G) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {

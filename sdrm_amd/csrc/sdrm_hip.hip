@@ -155,6 +155,9 @@ const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
 constexpr int SMALL_LAUNCH_BLOCKS32 = 256;
 int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
 int g_chains = -1;     // sampler row chains: -1 = by size, 1..4 forced (SDRM_CHAINS env / sdrm_debug_set_chains)
+int g_fuse_rev = 1;    // reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX sampling):
+                       // 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always (SDRM_FUSE_REV env)
+constexpr int FUSE_REV_MAX_ROWS = 1024;   // measured (tools/shard_probe.py): 679 rows 27.3 -> 24.7 us per step, 1358 rows 32.1 -> 32.6, 5429 rows 54.3 -> 56.9
 int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
 
 int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
@@ -440,6 +443,11 @@ int sdrm_debug_set_skinny(int on) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_fused_reverse(int mode) {
+  g_fuse_rev = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_chains(int chains) {
   g_chains = chains;
   return SDRM_OK;
@@ -467,6 +475,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     return SDRM_ERR_SHAPE;
   if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
   if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_FUSE_REV")) g_fuse_rev = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) g_wgrad_blocks = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
@@ -1033,12 +1042,27 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       }
       int rc = hidden_forward(e, MP, rows, sc, s0, PC_SMP_HIDDEN);
       if (rc) return rc;
+      float c1, sqrt_alpha, sqrt_beta;
+      reverse_coeffs(e, i, c1, sqrt_alpha, sqrt_beta);
+      const bool fused = !s.multires && s.mode == SDRM_RNG_PHILOX && (g_fuse_rev == 2 || (g_fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
       {
         GemmArgs a{};
         a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
         a.rows_valid = MP; a.cols_valid = e->LP;
+        const Prof pr{e, PC_SMP_OUT, 2.0 * rows * (double)e->L * e->W};
+        if (fused) {
+          // eps_hat never reaches memory: the epilogue applies denoise_add_noise to the sampler state and writes the
+          // next step's dropped-out input (one launch less per reverse step)
+          a.revX = e->X; a.revU = e->Us; a.rev_ldx = e->LP; a.rev_s0 = s0; a.rev_n = s1; a.rev_L = L; a.rev_step = i;
+          a.rev_c1 = c1; a.rev_sqrt_alpha = sqrt_alpha; a.rev_sqrt_beta = sqrt_beta; a.rev_nd = s.nd;
+          a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
+          a.rev_row0 = s.row0;
+          HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+                                                           e->LP, e->WP, sc, pr)));
+          continue;
+        }
         HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
-                                                          e->LP, e->WP, sc, Prof{e, PC_SMP_OUT, 2.0 * rows * (double)e->L * e->W})));
+                                                          e->LP, e->WP, sc, pr)));
       }
       ReverseArgs ra{};
       ra.X = e->X; ra.Y = e->Y; ra.U = e->Us;
@@ -1047,7 +1071,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ra.Tj = s.multires ? e->Tj_dev : nullptr;
       ra.rowid = s.multires ? e->rowid_dev : nullptr;
       ra.s0 = s0; ra.n = s1; ra.L = L; ra.LP = e->LP; ra.K0 = e->LP; ra.step_i = i; ra.nd = s.nd;
-      reverse_coeffs(e, i, ra.c1, ra.sqrt_alpha, ra.sqrt_beta);
+      ra.c1 = c1; ra.sqrt_alpha = sqrt_alpha; ra.sqrt_beta = sqrt_beta;
       ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
       ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
       hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, rows), dim3(256), 0, sc, ra);
