@@ -209,8 +209,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
+// The work-group body; `bid` is the work-group's index inside ITS problem (== blockIdx.x for a plain launch).
 template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
-__global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArgs p) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN, MF = Cfg::MF;
   constexpr int NR = (MF == 32) ? 16 : 4;      // accumulator registers per MFMA tile
   constexpr int KG = (MF == 32) ? 2 : 4;       // k consumed by one MFMA
@@ -248,12 +249,12 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     // split-K launch: all tiles of one K-slice go to ONE XCD (blocks are dealt round-robin over the 8
     // XCDs), so the slice's two operand strips (a few MB) are fetched from HBM once and re-read from that
     // XCD's L2 by the other tiles.  Spread over XCDs they were fetched 4.6x (measured: FETCH_SIZE).
-    const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int x = bid & 7, slot = bid >> 3;
     split = (slot / p.nblocks) * 8 + x;
     logical = slot % p.nblocks;
     if (split >= p.nsplits) return;
   } else {
-    logical = xcd_remap(blockIdx.x, p.nblocks);
+    logical = xcd_remap(bid, p.nblocks);
     split = 0;
   }
   const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
@@ -611,7 +612,7 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
 #ifdef SDRM_STAMPS
   if (EPI == EPI_PLAIN && p.stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
-    unsigned long long* o = p.stamps + 4 * (size_t)blockIdx.x;
+    unsigned long long* o = p.stamps + 4 * (size_t)bid;
     o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
   }
 #endif
@@ -622,11 +623,36 @@ __global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArg
     __syncthreads();
     if (lane == 0) smem[wave] = slope_sum;
     __syncthreads();
-    if (tid == 0) p.slope_partial[blockIdx.x] = smem[0] + smem[1] + smem[2] + smem[3];
+    if (tid == 0) p.slope_partial[bid] = smem[0] + smem[1] + smem[2] + smem[3];
   }
   if (EPI == EPI_SLAB) {
     if (do_dbias && (m0 + tid) < p.limA) p.dbias[(size_t)split * p.dbias_stride + m0 + tid] = dbsum;
   }
+}
+
+template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
+__global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_kernel(const GemmArgs p) {
+  gemm_body<Cfg, LOADA, LOADB, XFA, XFB, EPI>(p, (int)blockIdx.x);
+}
+
+// Several independent GEMMs of one kind in ONE launch (the weight gradients of all layers: every input is ready once
+// the dgrad chain is done): one ramp and one drain instead of one per layer, and the layers' work-groups fill each
+// other's tails.  Each problem owns the grid range [start[k], start[k+1]); the ranges are multiples of 8 work-groups,
+// so a work-group's XCD (blockIdx.x & 7) is also its XCD inside the problem.
+constexpr int GEMM_BATCH_MAX = 8;
+struct GemmBatch {
+  GemmArgs p[GEMM_BATCH_MAX];
+  int start[GEMM_BATCH_MAX + 1];
+  int n;
+};
+
+template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
+__global__ __launch_bounds__(NTHREADS, Cfg::MINW) void gemm_batch_kernel(const GemmBatch b) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < GEMM_BATCH_MAX; ++j)
+    if (j < b.n && (int)blockIdx.x >= b.start[j]) k = j;
+  gemm_body<Cfg, LOADA, LOADB, XFA, XFB, EPI>(b.p[k], (int)blockIdx.x - b.start[k]);
 }
 
 }  // namespace sdrm

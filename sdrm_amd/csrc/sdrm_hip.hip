@@ -57,6 +57,7 @@ struct sdrm_engine {
   const float* grad_src = nullptr;   // where the last backward wrote the flat gradient (internal g or the caller's buffer)
   float *rev_dev = nullptr;          // [3][T+1] reverse-step coefficients c1, sqrt(alpha), sqrt(beta)
   SelectState* sel = nullptr;        // radix-select workspace of sdrm_equal_sparsity
+  float* one_dev = nullptr;          // 1.0f (identity PReLU slope for layer 0 inside the batched weight-gradient launch)
   std::vector<int> smp_nact, smp_perm;
   std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
   std::vector<float> h_beta, h_alpha, h_alphabar;
@@ -67,7 +68,7 @@ struct sdrm_engine {
   bool fwd_done = false;
   int last_S = 1, last_dgrad_blocks = 0;
   bool bwd_begun = false;
-  int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
+  int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
@@ -99,7 +100,8 @@ enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, P
 static const char* kProfNames[PC_COUNT] = {
     "train: gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
     "train: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)",
-    "train: gemm_kernel<0,0,0,0,3> dgrad (prelu' epilogue)", "train: gemm_kernel<1,1,0,1,4> wgrad (prelu-in, split-K slabs)",
+    "train: gemm_kernel<0,0,0,0,3> dgrad (prelu' epilogue)",
+    "train: gemm_batch_kernel<1,1,0,1,4> wgrad of all layers in one launch (prelu-in, split-K slabs)",
     "train: gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)",
     "sample: gemm_kernel<0,0,0,0,0> fwd layer0 (bias table)", "sample: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
     "sample: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)"};
@@ -256,6 +258,48 @@ hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int
   a.slab_stride = (size_t)Nout * Kin;
   a.dbias = dbias; a.dbias_stride = Nout;
   return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st, pr);
+}
+
+// One weight gradient of a batched launch (gemm_batch_kernel): the arguments gemm_wgrad would pass, with the grid
+// bookkeeping launch_gemm_cfg does, for the default tile.  slopeB must be non-null: layer 0, whose operand is not a
+// stored pre-activation, passes a slope of exactly 1 (v > 0 ? v : 1*v is v bit for bit).
+struct WgradSpec {
+  const float* dC; int lddc, Nout; const float* Act; int ldact, Kin; const float* slopeB; int S, kchunk; float* slab; float* dbias;
+};
+
+hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mrows, hipStream_t st, Prof pr) {
+  GemmBatch b{};
+  b.n = n;
+  int grid = 0;
+  for (int k = 0; k < n; ++k) {
+    GemmArgs& a = b.p[k];
+    a.A = w[k].dC; a.lda = w[k].lddc; a.limA = w[k].Nout;
+    a.B = w[k].Act; a.ldb = w[k].ldact; a.limB = w[k].Kin;
+    a.C = w[k].slab; a.ldc = w[k].Kin;
+    a.K = Mrows; a.kchunk = w[k].kchunk;
+    a.slopeB = w[k].slopeB;
+    a.slab_stride = (size_t)w[k].Nout * w[k].Kin;
+    a.dbias = w[k].dbias; a.dbias_stride = w[k].Nout;
+    const int tiles_m = (w[k].Nout + Cfg0::BM - 1) / Cfg0::BM, tiles_n = (w[k].Kin + Cfg0::BN - 1) / Cfg0::BN;
+    a.tiles_n = tiles_n; a.nblocks = tiles_m * tiles_n; a.nsplits = w[k].S;
+    b.start[k] = grid;
+    grid += a.nblocks * ((w[k].S + 7) / 8) * 8;   // a multiple of 8: the XCD of a work-group is the same inside its problem
+  }
+  b.start[n] = grid;
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(pr.cls);
+    e->prof_flops.push_back(pr.flops);
+    hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
+    if (st0 != hipSuccess) return st0;
+  }
+  hipLaunchKernelGGL((gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_PRELU, EPI_SLAB>), dim3((unsigned)grid),
+                     dim3(NTHREADS), 0, st, b);
+  hipError_t rc = hipGetLastError();
+  if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
+  return rc;
 }
 
 void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
@@ -511,6 +555,11 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
   HIP_TRY(e, dalloc(&e->sel, 1));
+  HIP_TRY(e, dalloc(&e->one_dev, 4));
+  {
+    const float one = 1.0f;
+    HIP_TRY(e, hipMemcpy(e->one_dev, &one, 4, hipMemcpyHostToDevice));
+  }
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
   HIP_TRY(e, dalloc(&e->dA, (size_t)(H + 1) * MP * e->WP));   // dpre_buf(0..H)
@@ -544,7 +593,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -687,7 +736,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
 namespace {
 
 // loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
-int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st) {
+int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
   SeedArgs sa{};
   sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
@@ -713,23 +762,54 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     HIP_TRY(e, gemm_dgrad(e, dpre_buf(e, k), e->WP, e->WhcT, e->WP, MP, e->WP, e->WP, dpre_buf(e, k - 1), pre_buf(e, k - 1),
                           slope_ptr(e, k - 1), e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, st, flH, cfg_d));
   // layer 0 (no latent dgrad: XT.grad is never read, Q7)
-  HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
-                                  Prof{e, PC_WGRAD_L0, fl0})));
+  if (with_wgrad0)
+    HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                    Prof{e, PC_WGRAD_L0, fl0})));
+  e->bwd_kc0 = kc0;
   e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
   e->bwd_kcH = kcH; e->bwd_kcO = kcO;
   return SDRM_OK;
 }
 
-// weight gradients of the output and hidden layers: two thirds of the wgrad flops, only Adam waits for them
-int backward_upper_wgrads(sdrm_engine* e, hipStream_t st) {
+// weight gradients of the output and hidden layers (two thirds of the wgrad flops, only Adam waits for them), and, for
+// the one-call backward, of layer 0 as well: ONE batched launch (gemm_batch_kernel) - every input is ready once the
+// dgrad chain is done.  More problems than a batch holds (H > 6) go in several batches; a forced tile shape
+// (SDRM_TILE) falls back to one launch per layer.
+int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
-  HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
-                                   e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
-  for (int k = H; k >= 1; --k)
-    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
-                                     e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
-                                     e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
+  const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
+  if (g_force_cfg > 0) {
+    if (with_wgrad0)
+      HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, e->bwd_S0, e->bwd_kc0, e->slab0,
+                                      e->db0s, st, Prof{e, PC_WGRAD_L0, fl0})));
+    HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
+                                     e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
+    for (int k = H; k >= 1; --k)
+      HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
+                                       e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
+                                       e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
+    return SDRM_OK;
+  }
+  std::vector<WgradSpec> w;
+  std::vector<double> fl;
+  if (with_wgrad0) {
+    w.push_back(WgradSpec{dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, e->one_dev, e->bwd_S0, e->bwd_kc0, e->slab0, e->db0s});
+    fl.push_back(fl0);
+  }
+  w.push_back(WgradSpec{e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), SO, e->bwd_kcO, e->slabO, e->dbOs});
+  fl.push_back(flO);
+  for (int k = H; k >= 1; --k) {
+    w.push_back(WgradSpec{dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), SH, e->bwd_kcH,
+                          e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP, e->dbHs + (size_t)(k - 1) * SH * e->WP});
+    fl.push_back(flH);
+  }
+  for (size_t lo = 0; lo < w.size(); lo += GEMM_BATCH_MAX) {
+    const int n = (int)std::min<size_t>(GEMM_BATCH_MAX, w.size() - lo);
+    double f = 0.0;
+    for (int k = 0; k < n; ++k) f += fl[lo + k];
+    HIP_TRY(e, launch_wgrad_batch(e, w.data() + lo, n, MP, st, Prof{e, PC_WGRAD, f}));
+  }
   return SDRM_OK;
 }
 
@@ -773,7 +853,7 @@ int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, f
   e->bwd_begun = false;
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
-  int rc = backward_chain(e, sums, loss, st);
+  int rc = backward_chain(e, sums, loss, st, true);
   if (!rc) rc = backward_finalize(e, gout, BUCKET_FIRST, st);
   if (!rc) rc = backward_embedding(e, gout, st);
   if (rc) return rc;
@@ -787,7 +867,7 @@ int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   float* gout = grad ? grad : e->g;
   if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_finish: different gradient buffer than begin");
-  int rc = backward_upper_wgrads(e, st);
+  int rc = backward_wgrads(e, st, false);
   if (!rc) rc = backward_finalize(e, gout, BUCKET_SECOND, st);
   e->bwd_begun = false;
   return rc;
@@ -801,8 +881,8 @@ int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* 
   e->bwd_begun = false;
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
-  int rc = backward_chain(e, sums, loss, st);
-  if (!rc) rc = backward_upper_wgrads(e, st);
+  int rc = backward_chain(e, sums, loss, st, false);
+  if (!rc) rc = backward_wgrads(e, st, true);
   if (!rc) rc = backward_finalize(e, gout, BUCKET_BOTH, st);
   if (!rc) rc = backward_embedding(e, gout, st);
   return rc;
