@@ -307,9 +307,28 @@ __global__ __launch_bounds__(256) void k_loss_sums(const double* part, int nblk,
 struct SeedArgs {
   const double* sums; const float* Y; const float* x0; float* dY; float* loss;
   int B, L, LP, MP;
+  // single-GPU fused step: sums == null and every block folds the k_loss_partials output itself (same reduction tree
+  // as k_loss_sums, so the same bits) - one launch less per train step
+  const double* part; int nblk; double count;
 };
 
 __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
+  // the five sums first: the fold below has block barriers, so it sits ahead of every early exit
+  double s0, s1, s2, s3, N;
+  if (a.sums) {
+    s0 = a.sums[0]; s1 = a.sums[1]; s2 = a.sums[2]; s3 = a.sums[3]; N = a.sums[4];
+  } else {
+    __shared__ double shs[4], tot[4];
+    double v[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x)
+      for (int j = 0; j < 4; ++j) v[j] += a.part[4 * (size_t)i + j];
+    for (int j = 0; j < 4; ++j) {
+      const double t = block_sum(v[j], shs);
+      if (threadIdx.x == 0) tot[j] = t;
+    }
+    __syncthreads();
+    s0 = tot[0]; s1 = tot[1]; s2 = tot[2]; s3 = tot[3]; N = a.count;
+  }
   const int QP = a.LP >> 2;
   const size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int r = (int)(flat / QP);
@@ -321,10 +340,9 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
     if (row < a.MP) *reinterpret_cast<float4*>(a.dY + (size_t)row * a.LP + c) = zero;
     return;
   }
-  const double N = a.sums[4];
-  const double A = a.sums[0] / N, C = a.sums[1] / N, Rbar = a.sums[2] / N;
+  const double A = s0 / N, C = s1 / N, Rbar = s2 / N;
   // unbiased variance; a single element gives 0/0 = NaN exactly as torch.var does (train_SDRM.py:198)
-  const double V = (N > 1.0) ? (a.sums[3] - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
+  const double V = (N > 1.0) ? (s3 - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
   const double den = 1e-8 + V;
   const double k = 0.5 / den;
   if (r == 0 && c == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);

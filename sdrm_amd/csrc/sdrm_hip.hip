@@ -68,6 +68,7 @@ struct sdrm_engine {
   bool fwd_done = false;
   int last_S = 1, last_dgrad_blocks = 0;
   bool bwd_begun = false;
+  bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
@@ -718,9 +719,11 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
   hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(256), 0, st, la);
   HIP_TRY(e, hipGetLastError());
-  hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
-                     (double)B * (double)e->L, sums ? sums : e->sums);
-  HIP_TRY(e, hipGetLastError());
+  if (!e->fold_sums) {
+    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
+                       (double)B * (double)e->L, sums ? sums : e->sums);
+    HIP_TRY(e, hipGetLastError());
+  }
   e->cur_B = B; e->cur_MP = MP; e->cur_x0 = x0; e->fwd_done = true;
   return SDRM_OK;
 }
@@ -739,8 +742,9 @@ namespace {
 int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
   SeedArgs sa{};
-  sa.sums = sums ? sums : e->sums; sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
+  sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
+  sa.part = e->loss_part; sa.nblk = LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
   {
     dim3 grid((unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256));
     hipLaunchKernelGGL(k_loss_seed, grid, dim3(256), 0, st, sa);
@@ -904,9 +908,11 @@ int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
 
 int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,
                     uint64_t seed, uint64_t step, float nd, float* loss, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  e->fold_sums = true;    // one process, one GPU: nobody needs the five sums between the forward and the backward
   int rc = sdrm_train_forward(e, x0, B, 0, mode, rnd, seed, step, nd, nullptr, stream);
-  if (rc) return rc;
-  rc = sdrm_train_backward(e, nullptr, nullptr, loss, stream);
+  if (!rc) rc = sdrm_train_backward(e, nullptr, nullptr, loss, stream);
+  e->fold_sums = false;
   if (rc) return rc;
   return sdrm_adam_step(e, nullptr, lr, stream);
 }
