@@ -227,10 +227,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   // of fragments with BK/8 ds_read_b128 per MFMA tile edge instead of BK/2 ds_read_b32.  The MFMA contraction
   // does not care which k a (group, lane-half) slot carries as long as A and B agree: lane-half h takes
   // k = h*BK/2 .. h*BK/2 + BK/2-1 of the K-step.
-  constexpr bool KM = (LOADA == LD_KCONTIG && LOADB == LD_KCONTIG && MF == 32);
+  // (16-wide MFMA: lane group q = lane>>4 takes k = 16u + 4q + e of the K-step for MFMA (u, e), u < BK/16 - the same
+  //  permutation trick, one ds_read_b128 per u)
+  constexpr bool KM = (LOADA == LD_KCONTIG && LOADB == LD_KCONTIG);
   constexpr int LDK = Cfg::LDK;
   constexpr int BOFF = KM ? BM * LDK : BK * LDA;   // B operand's offset inside a stage
-  constexpr int NQ = BK / 8;                       // float4 fragments per lane per MFMA tile edge per K-step
+  constexpr int NQ = (MF == 32) ? BK / 8 : BK / 16;   // float4 fragments per lane per MFMA tile edge per K-step
+  constexpr int QSTEP = (MF == 32) ? 4 : 16;          // distance (floats) between a lane's consecutive fragments
   constexpr int NVA = BM * BK / 4 / NTHREADS, NVB = BN * BK / 4 / NTHREADS;
   static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 loader threads");
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
@@ -302,8 +305,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   // column: 352 = 5.5 x 64) issues no LDS reads and no MFMAs; it still loads, stores and meets the
   // barriers.  Its SIMD's matrix pipe goes to the other work-groups resident on the CU.
   const bool wave_active = (m0 + wm * (BM / Cfg::WM) < p.limA) && (n0 + wn * (BN / Cfg::WN) < p.limB);
-  const int aoffk = (wm * (BM / Cfg::WM) + l31) * LDK + (BK / 2) * lhi;
-  const int boffk = (wn * (BN / Cfg::WN) + l31) * LDK + (BK / 2) * lhi;
+  const int aoffk = (wm * (BM / Cfg::WM) + l31) * LDK + ((MF == 32) ? (BK / 2) : 4) * lhi;
+  const int boffk = (wn * (BN / Cfg::WN) + l31) * LDK + ((MF == 32) ? (BK / 2) : 4) * lhi;
 
   if constexpr (KM) {
     // NT main loop.  A wave issues in order and its MFMAs form one dependent chain per accumulator tile, so the
@@ -324,9 +327,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a) fa[a][q] = *reinterpret_cast<const float4*>(As + aoffk + MF * a * LDK + 4 * q);
+        for (int a = 0; a < TM; ++a) fa[a][q] = *reinterpret_cast<const float4*>(As + aoffk + MF * a * LDK + QSTEP * q);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) fb[b][q] = *reinterpret_cast<const float4*>(Bs + boffk + MF * b * LDK + 4 * q);
+        for (int b = 0; b < TN; ++b) fb[b][q] = *reinterpret_cast<const float4*>(Bs + boffk + MF * b * LDK + QSTEP * q);
       }
     };
     // one K-step: MFMAs out of (ca, cb); pieces: read (na, nb) from stage rs, store (xa, xb) into stage ss, load step li
@@ -347,7 +350,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
             for (int b = 0; b < TN; ++b) {
               const float av = j == 0 ? ca[a][q].x : j == 1 ? ca[a][q].y : j == 2 ? ca[a][q].z : ca[a][q].w;
               const float bv = j == 0 ? cb[b][q].x : j == 1 ? cb[b][q].y : j == 2 ? cb[b][q].z : cb[b][q].w;
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+              if constexpr (MF == 32) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a][b], 0, 0, 0);
+              else acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[a][b], 0, 0, 0);
             }
         }
         // the piece that rides in this group's shadow
@@ -356,10 +360,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
             const int rq = sl >> 1;
             if ((sl & 1) == 0) {
 #pragma unroll
-              for (int a = 0; a < TM; ++a) na[a][rq] = *reinterpret_cast<const float4*>(Ar + aoffk + MF * a * LDK + 4 * rq);
+              for (int a = 0; a < TM; ++a) na[a][rq] = *reinterpret_cast<const float4*>(Ar + aoffk + MF * a * LDK + QSTEP * rq);
             } else {
 #pragma unroll
-              for (int b = 0; b < TN; ++b) nb[b][rq] = *reinterpret_cast<const float4*>(Br + boffk + MF * b * LDK + 4 * rq);
+              for (int b = 0; b < TN; ++b) nb[b][rq] = *reinterpret_cast<const float4*>(Br + boffk + MF * b * LDK + QSTEP * rq);
             }
           }
         } else if (sl == 2 * NQ) {

@@ -151,11 +151,6 @@ typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16
 constexpr int N_TILE_CFGS = 5;
 const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
 const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
-// A launch whose 32x32 tiling still fits one work-group per CU (<= 256 blocks) runs on the 16-wide MFMA with
-// 32x32x32 tiles: its time is then one block's chain of dependent MFMAs, a quarter of the 64x64 tile's, and four
-// times as many CUs take part.  Measured crossover (tools/gemm_tune.py, N=K=352): 704 rows 242 blocks faster
-// on 32x32, 1024 rows (352 blocks, a second round on some CUs) faster on 64x64.
-constexpr int SMALL_LAUNCH_BLOCKS32 = 256;
 int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
 int g_chains = -1;     // sampler row chains: -1 = by size, 1..4 forced (SDRM_CHAINS env / sdrm_debug_set_chains)
 int g_fuse_rev = 1;    // reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX sampling):
@@ -167,9 +162,18 @@ int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
   return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
 }
 
+int g_nt32_max_rows = 4096;   // NT launches of at most this many rows use the 32x32 tile (SDRM_NT32_MAX_ROWS env: tuning aid)
+
+// Tile for an unsplit (NT) launch.  With the k-minor LDS image and ds_read_b128 fragments the 32x32x32 tile on the
+// 16-wide MFMA has no ragged tile (352 = 11 x 32), four times the work-groups and a quarter of the dependent MFMA
+// chain per wave.  Stand-alone (tools/gemm_tune.py, operands hot in L2) it matches or beats 64x64x16 at every size;
+// inside the step, where every operand was just written by the previous launch, it wins up to a few thousand rows
+// and loses above (tools/shard_probe.py, sample step at 679 / 1358 / 2715 / 5429 rows: 19.3 / 25.6 / 36.9 / 60.1 us
+// against 23.5 / 31.6 / 49.9 / 54.2; train step at 3072 / 6144 / 12288 / 24576 stacked rows: 156 / 235 / 375 / 683
+// against 170 / 235 / 363 / 629) - twice the operand traffic through L2 per flop.
 int choose_cfg(int M, int N, int K) {
   int cfg = pick_cfg(M, N, K);
-  if (cfg == 0 && g_force_cfg < 0 && ((M + 31) / 32) * ((N + 31) / 32) <= SMALL_LAUNCH_BLOCKS32) cfg = 4;
+  if (cfg == 0 && g_force_cfg < 0 && M <= g_nt32_max_rows) cfg = 4;
   return cfg;
 }
 
@@ -521,6 +525,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
   if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
   if (const char* env = std::getenv("SDRM_FUSE_REV")) g_fuse_rev = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) g_nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) g_wgrad_blocks = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
