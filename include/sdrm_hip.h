@@ -219,9 +219,9 @@ int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const i
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);
 /* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;
- * every other case uses the stand-alone k_reverse_update): 0 never, 1 (default) for launches of at most 1024 rows - the
- * latency-bound shards of a multi-GPU run, where one launch less per reverse step is worth more than the epilogue's
- * Philox work - 2 always; also env SDRM_FUSE_REV.  Results are identical up to the rounding of the update arithmetic.
+ * every other case uses the stand-alone k_reverse_update): 0 never, 1 (default) for launches of at most 4096 rows - the
+ * shards of a multi-GPU run, which run on the 32x32 tile where one launch less per reverse step is worth more than the
+ * epilogue's Philox work - 2 always; also env SDRM_FUSE_REV.  Results are identical up to the rounding of the update arithmetic.
  * Test / tuning aid. */
 int sdrm_debug_set_fused_reverse(int mode);
 /* Row chains of a sampling call (csrc/sdrm_hip.hip: independent row ranges run on separate HIP streams so that one

@@ -155,7 +155,9 @@ int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning a
 int g_chains = -1;     // sampler row chains: -1 = by size, 1..4 forced (SDRM_CHAINS env / sdrm_debug_set_chains)
 int g_fuse_rev = 1;    // reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX sampling):
                        // 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always (SDRM_FUSE_REV env)
-constexpr int FUSE_REV_MAX_ROWS = 1024;   // measured (tools/shard_probe.py): 679 rows 27.3 -> 24.7 us per step, 1358 rows 32.1 -> 32.6, 5429 rows 54.3 -> 56.9
+constexpr int FUSE_REV_MAX_ROWS = 4096;   // = the launches that run on the 32x32 tile (4 accumulator rows per lane: two Philox calls);
+                                          // measured (tools/shard_probe.py): 679 / 1358 / 2715 rows 21.1 / 24.9 / 36.6 -> 18.8 / 22.6 / 33.7 us per step;
+                                          // on the 64x64 tile (16 rows per lane) 5429 rows 54.3 -> 56.9
 int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
 
 int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
