@@ -139,15 +139,15 @@ const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
 struct Prof { sdrm_engine* e; int cls; double flops; };
 
-// Tile shapes.  Measured on MI355X (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep.txt): the smallest
-// tile with the shortest K-step wins on every shape of this workload (103 TF at 24576x352x352 vs 78 TF
-// for 128x128x16): K is only ~350 deep, so a block is mostly prologue/epilogue and per-K-step barrier
-// latency, and what hides that is many co-resident blocks (17 KB of LDS -> 9 per CU), not a big tile.
+// Tile shapes (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep_c.txt).  K is only ~350 deep, so a work-group is ~22
+// K-steps long and what hides its prologue, epilogue and per-K-step barrier is many co-resident work-groups, not a
+// big tile: 64x64x16 (20 KB of LDS, <= 80 VGPRs -> six per CU) for the large launches, 32x32x32 on the 16-wide MFMA
+// for NT launches of up to 4096 rows (choose_cfg), the others are tuning alternates (SDRM_TILE).
 typedef TileCfg<64, 64, 2, 2, 4, 16> Cfg0;     //  64x 64x16  (default)
 typedef TileCfg<64, 64, 2, 2, 4, 32, 32, 1> Cfg1;  //  64x 64x32, one prefetch set
 typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
 typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
-typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32: launches too small to fill the chip
+typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32 (NT launches of <= 4096 rows)
 constexpr int N_TILE_CFGS = 5;
 const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
 const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
@@ -172,7 +172,9 @@ int g_nt32_max_rows = 4096;   // NT launches of at most this many rows use the 3
 // inside the step, where every operand was just written by the previous launch, it wins up to a few thousand rows
 // and loses above (tools/shard_probe.py, sample step at 679 / 1358 / 2715 / 5429 rows: 19.3 / 25.6 / 36.9 / 60.1 us
 // against 23.5 / 31.6 / 49.9 / 54.2; train step at 3072 / 6144 / 12288 / 24576 stacked rows: 156 / 235 / 375 / 683
-// against 170 / 235 / 363 / 629) - twice the operand traffic through L2 per flop.
+// against 170 / 235 / 363 / 629) - the 64x64 tile moves half
+// the operand bytes per flop.  (64x32 and 32x64 tiles on the 16-wide MFMA were tried for the large launches: 644 / 661 us per
+// train step against 618.)
 int choose_cfg(int M, int N, int K) {
   int cfg = pick_cfg(M, N, K);
   if (cfg == 0 && g_force_cfg < 0 && M <= g_nt32_max_rows) cfg = 4;
