@@ -54,13 +54,22 @@ def _interleave(a0, a1, L):
 
 
 def train_randoms(seed, step, row0, B, L, T, nd):
-    """eps [B,L] f32 (already * nd), t [B] i64, keep [3,B,L] u8 — what k_prep_train draws."""
-    rows, pairs = _grid(row0, B, L)
-    x, y, z, _ = philox4x32_10(rows, pairs, PURPOSE_TRAIN_ELEM, step, seed)
-    n0, n1 = box_muller(x, y)
-    eps = _interleave(n0, n1, L) * np.float32(nd)
-    keep = np.stack([_interleave(((z >> np.uint64(k)) & np.uint64(1)).astype(np.uint8),
-                                 ((z >> np.uint64(8 + k)) & np.uint64(1)).astype(np.uint8), L) for k in range(3)])
+    """eps [B,L] f32 (already * nd), t [B] i64, keep [3,B,L] u8 — what k_prep_train draws: one Philox call per group of
+    four columns (counter = column quad): (x, y) and (z, w) are two Box-Muller pairs, the low byte of word j holds the
+    three keep bits (passes P, S, Q) of column j."""
+    rows = (np.arange(B, dtype=np.uint64) + np.uint64(row0))[:, None]
+    quads = np.arange((L + 3) // 4, dtype=np.uint64)[None, :]
+    words = philox4x32_10(rows, quads, PURPOSE_TRAIN_ELEM, step, seed)
+    n0, n1 = box_muller(words[0], words[1])
+    n2, n3 = box_muller(words[2], words[3])
+    eps = np.empty((B, 4 * quads.shape[1]), dtype=np.float32)
+    eps[:, 0::4], eps[:, 1::4], eps[:, 2::4], eps[:, 3::4] = n0, n1, n2, n3
+    eps = eps[:, :L] * np.float32(nd)
+    keep = np.empty((3, B, 4 * quads.shape[1]), dtype=np.uint8)
+    for k in range(3):
+        for j in range(4):
+            keep[k, :, j::4] = ((words[j] >> np.uint64(k)) & np.uint64(1)).astype(np.uint8)
+    keep = np.ascontiguousarray(keep[:, :, :L])
     tx, _, _, _ = philox4x32_10(rows[:, 0], 0, PURPOSE_TRAIN_T, step, seed)
     t = 1 + bounded(tx, T)
     return eps.astype(np.float32), t, keep

@@ -122,24 +122,36 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
   // one thread per group of four columns of one staged row triple (16-byte stores; the row's t is drawn once
   // per thread instead of once per column pair)
   const int QP = a.K0 >> 2;
-  const int64_t i = (int64_t)((int)blockIdx.x - a.emb_blocks) * 256 + threadIdx.x;
+  const int64_t i0 = (int64_t)((int)blockIdx.x - a.emb_blocks) * 256;
+  const int64_t i = i0 + threadIdx.x;
   const int r = (int)(i / QP);
   const int c = 4 * (int)(i - (int64_t)r * QP);
+  // the timesteps of the (at most 18: K0 >= 64) rows this block touches, drawn once per row
+  __shared__ int tts[20];
+  const int r_first = (int)(i0 / QP), r_last = (int)((i0 + 255) / QP);
+  if ((int)threadIdx.x <= r_last - r_first) {
+    const int rr = r_first + (int)threadIdx.x;
+    int t0 = 0;
+    if (rr < a.B) {
+      if (a.mode == 0) {
+        t0 = (int)a.t[rr];
+      } else {
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + rr), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
+        t0 = 1 + (int)bounded(w.x, (uint32_t)a.T);
+      }
+      t0 = min(max(t0, 0), a.T);
+      a.tdev[rr] = t0;   // (rows shared by two blocks are written twice with the same value)
+    }
+    tts[threadIdx.x] = t0;
+  }
+  __syncthreads();
   if (r >= a.emb_row0) return;
   if (r >= a.B) {  // zero pad rows
     const int row = 3 * a.B + (r - a.B);
     if (row < a.MP) *reinterpret_cast<float4*>(a.U + (size_t)row * a.K0 + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
-  int tt;
-  if (a.mode == 0) {
-    tt = (int)a.t[r];
-  } else {
-    const U4 w = philox4x32_10((uint32_t)(a.row0 + r), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
-    tt = 1 + (int)bounded(w.x, (uint32_t)a.T);
-  }
-  tt = min(max(tt, 0), a.T);
-  if (c == 0) a.tdev[r] = tt;
+  const int tt = tts[r - r_first];
   float vP[4] = {0.f, 0.f, 0.f, 0.f}, vS[4] = {0.f, 0.f, 0.f, 0.f}, vQ[4] = {0.f, 0.f, 0.f, 0.f};
   if (c < a.LP) {
     if (c < a.L) {
@@ -147,16 +159,17 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
       const float4 X = load4_unpadded(a.x0, r, c, a.L);
       const float x_[4] = {X.x, X.y, X.z, X.w};
       float e[4] = {0.f, 0.f, 0.f, 0.f};
-      uint32_t bits[2] = {0u, 0u};
+      uint32_t bits[4] = {0u, 0u, 0u, 0u};
       if (a.mode != 0) {
+        // ONE Philox call per group of four columns: (x, y) and (z, w) give two normal pairs (the upper 24 bits of
+        // each word), the low byte of word j carries the three keep bits of column j (integer multiplies are what
+        // this kernel is bound by; the counter is the column quad)
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)(c >> 2), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo, a.seed_hi);
+        box_muller(w.x, w.y, e[0], e[1]);
+        box_muller(w.z, w.w, e[2], e[3]);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {   // the counter is the column PAIR (same stream as the 2-column form)
-          const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)(c / 2 + h), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo,
-                                     a.seed_hi);
-          box_muller(w.x, w.y, e[2 * h], e[2 * h + 1]);
-          e[2 * h] *= a.nd; e[2 * h + 1] *= a.nd;
-          bits[h] = w.z;
-        }
+        for (int j = 0; j < 4; ++j) e[j] *= a.nd;
+        bits[0] = w.x; bits[1] = w.y; bits[2] = w.z; bits[3] = w.w;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
             k1 = a.keep[idx] != 0; k2 = a.keep[BL + idx] != 0; k3 = a.keep[2 * BL + idx] != 0;
           } else {
             ee = e[j];
-            const uint32_t bb = bits[j >> 1] >> (8 * (j & 1));
+            const uint32_t bb = bits[j];
             k1 = bb & 1u; k2 = (bb >> 1) & 1u; k3 = (bb >> 2) & 1u;
           }
           const float xp = sa * x + om * ee;
