@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
 SOURCES = ["sdrm_hip.hip"]
-HEADERS = ["gemm.h", "elementwise.h", "philox.h", "skinny.h", "select.h", "rank.h", "feed.h", os.path.join("..", "..", "include", "sdrm_hip.h")]
+HEADERS = ["gemm.h", "skinny_train.h", "elementwise.h", "philox.h", "skinny.h", "select.h", "rank.h", "feed.h", os.path.join("..", "..", "include", "sdrm_hip.h")]
 LIB_PATH = os.path.join(HERE, "libsdrm_hip.so")
 
 

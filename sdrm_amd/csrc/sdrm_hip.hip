@@ -17,6 +17,7 @@
 #include "rank.h"
 #include "select.h"
 #include "skinny.h"
+#include "skinny_train.h"
 
 using namespace sdrm;
 
@@ -158,7 +159,8 @@ int g_fuse_rev = 1;    // reverse update fused into the out-layer GEMM epilogue 
 constexpr int FUSE_REV_MAX_ROWS = 4096;   // = the launches that run on the 32x32 tile (4 accumulator rows per lane: two Philox calls);
                                           // measured (tools/shard_probe.py): 679 / 1358 / 2715 rows 21.1 / 24.9 / 36.6 -> 18.8 / 22.6 / 33.7 us per step;
                                           // on the 64x64 tile (16 rows per lane) 5429 rows 54.3 -> 56.9
-int g_skinny = 1;      // persistent LDS-resident sampler for nets with padded widths <= 64 (sdrm_debug_set_skinny)
+int g_skinny = 1;      // LDS-resident kernels for nets with padded widths <= 64: persistent sampler, fused train forward and
+                       // dgrad chain (sdrm_debug_set_skinny)
 
 int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
   return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
@@ -395,6 +397,50 @@ int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
   return SDRM_OK;
 }
 
+bool skinny_net(const sdrm_engine* e) { return g_skinny && e->LP <= 64 && e->WP <= 64; }
+
+SkinnyTrainArgs skinny_train_args(sdrm_engine* e, int B, int MP) {
+  SkinnyTrainArgs a{};
+  const int n = e->T + 1;
+  a.W0c = e->W0c; a.K0 = e->K0; a.Whc = e->Whc; a.Woc = e->Woc; a.bh = e->bhc; a.bo = e->boc;
+  a.WhcT = e->WhcT; a.WocT = e->WocT; a.B0tab = e->B0tab;
+  a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
+  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n;
+  a.B = B; a.L = e->L; a.W = e->W; a.T = e->T; a.H = e->H; a.MP = MP; a.LPs = e->LP; a.WPs = e->WP;
+  a.U = e->U; a.tdev = e->tdev; a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.Y = e->Y;
+  a.dY = e->dY; a.dpre = e->dA; a.alpha_part = e->alpha_part; a.alpha_part_stride = e->alpha_part_stride;
+  return a;
+}
+
+// one of the two fused skinny train kernels (fwd: which = 0, dgrad chain: which = 1) on MP stacked rows:
+// one work-group per 16 rows, one wave per 16-column tile
+int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hipStream_t st) {
+  const int NL = (e->L + 15) / 16, NW = (e->W + 15) / 16;   // tiles with real columns (1..4 each)
+  dim3 grid(ka.MP / 16), block(64 * (NL > NW ? NL : NW));
+#define SKT_LAUNCH(nl, nw)                                                                         \
+  do {                                                                                             \
+    if (which == 0) hipLaunchKernelGGL((k_skinny_train_fwd<nl, nw>), grid, block, 0, st, ka);      \
+    else hipLaunchKernelGGL((k_skinny_train_bwd<nl, nw>), grid, block, 0, st, ka);                 \
+  } while (0)
+#define SKT_ROW(nl)                                 \
+  switch (NW) {                                     \
+    case 1: SKT_LAUNCH(nl, 1); break;               \
+    case 2: SKT_LAUNCH(nl, 2); break;               \
+    case 3: SKT_LAUNCH(nl, 3); break;               \
+    default: SKT_LAUNCH(nl, 4); break;              \
+  }
+  switch (NL) {
+    case 1: SKT_ROW(1); break;
+    case 2: SKT_ROW(2); break;
+    case 3: SKT_ROW(3); break;
+    default: SKT_ROW(4); break;
+  }
+#undef SKT_ROW
+#undef SKT_LAUNCH
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
 // (its bias / K differ between training and sampling).
 int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int r0 = 0, int cls = PC_FWD_HIDDEN) {
@@ -580,7 +626,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     HIP_TRY(e, dalloc(&e->slabH, (size_t)H * S_MAX * e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->dbHs, (size_t)H * S_MAX * e->WP));
   }
-  e->alpha_part_stride = max_gemm_blocks((int)MP, e->WP);
+  e->alpha_part_stride = std::max(max_gemm_blocks((int)MP, e->WP), (int)MP / 16);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
   HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
   HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
@@ -693,6 +739,30 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   e->fwd_done = false;
 
+  if (skinny_net(e)) {
+    // narrow net: tables (B0tab = b0 + C0[t], E for the embedding backward), then staging and all layers in one launch
+    int rc = emb_tables(e, true, st);
+    if (rc) return rc;
+    SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
+    ka.x0 = x0;
+    if (mode == SDRM_RNG_EXPLICIT) { ka.noise = rnd->noise; ka.t = rnd->t; ka.keep = rnd->keep; }
+    ka.mode = mode; ka.seed_lo = (uint32_t)seed; ka.seed_hi = (uint32_t)(seed >> 32); ka.step = (uint32_t)step;
+    ka.row0 = row0; ka.nd = nd;
+    rc = launch_skinny_train(e, ka, 0, st);
+    if (rc) return rc;
+    LossArgs la{};
+    la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
+    hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(256), 0, st, la);
+    HIP_TRY(e, hipGetLastError());
+    if (!e->fold_sums) {
+      hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
+                         (double)B * (double)e->L, sums ? sums : e->sums);
+      HIP_TRY(e, hipGetLastError());
+    }
+    e->cur_B = B; e->cur_MP = MP; e->cur_x0 = x0; e->fwd_done = true;
+    return SDRM_OK;
+  }
+
   PrepTrainArgs pa{};
   pa.x0 = x0;
   if (mode == SDRM_RNG_EXPLICIT) { pa.noise = rnd->noise; pa.t = rnd->t; pa.keep = rnd->keep; }
@@ -768,6 +838,19 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
+  if (skinny_net(e)) {
+    // narrow net: the whole dgrad chain in one launch; one slope partial per application and work-group
+    const SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
+    int rc = launch_skinny_train(e, ka, 1, st);
+    if (rc) return rc;
+    if (with_wgrad0)
+      HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                      Prof{e, PC_WGRAD_L0, fl0})));
+    e->bwd_kc0 = kc0;
+    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = MP / 16;
+    e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+    return SDRM_OK;
+  }
   // dpre[k] = gradient w.r.t. pre-activation k (kept for the weight gradients that run later)
   HIP_TRY(e, gemm_dgrad(e, e->dY, e->LP, e->WocT, e->LP, MP, e->LP, e->WP, dpre_buf(e, H), pre_buf(e, H), slope_ptr(e, H),
                         e->alpha_part + (size_t)H * e->alpha_part_stride, st, flO, cfg_d));
@@ -1092,25 +1175,26 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ka.out = e->X; ka.n = n; ka.L = L; ka.W = e->W; ka.T = e->T; ka.H = e->H;
       ka.mode = s.mode; ka.seed_lo = (uint32_t)s.seed; ka.seed_hi = (uint32_t)(s.seed >> 32);
       ka.call_id = (uint32_t)s.call_id; ka.row0 = s.row0; ka.nd = s.nd;
-      const int NL = e->LP / 16, NW = e->WP / 16;
-      const int LD0 = e->LP + 4, LDH = e->WP + 4, SCR = (e->LP > e->WP ? e->LP : e->WP) + 4;
-      const size_t lds = (size_t)(e->WP * LD0 + e->WP * LDH + e->LP * LDH + 4 * 16 * SCR) * sizeof(float);
-      dim3 grid((n + 63) / 64);
-      hipError_t rc = hipSuccess;
-#define SKINNY_LAUNCH(nl, nw)                                                                                   \
-  do {                                                                                                          \
-    rc = hipFuncSetAttribute((const void*)k_skinny_sample<nl, nw>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (rc == hipSuccess) {                                                                                     \
-      hipLaunchKernelGGL((k_skinny_sample<nl, nw>), grid, dim3(256), lds, st, ka);                              \
-      rc = hipGetLastError();                                                                                   \
-    }                                                                                                           \
-  } while (0)
-      if (NL == 2 && NW == 2) SKINNY_LAUNCH(2, 2);
-      else if (NL == 2 && NW == 4) SKINNY_LAUNCH(2, 4);
-      else if (NL == 4 && NW == 2) SKINNY_LAUNCH(4, 2);
-      else SKINNY_LAUNCH(4, 4);
+      ka.LPs = e->LP; ka.WPs = e->WP;
+      const int NL = (L + 15) / 16, NW = (e->W + 15) / 16;           // tiles with real columns (1..4 each)
+      dim3 grid((n + 15) / 16), block(64 * (NL > NW ? NL : NW));   // 16 rows per work-group, one wave per column tile
+#define SKINNY_LAUNCH(nl, nw) hipLaunchKernelGGL((k_skinny_sample<nl, nw>), grid, block, 0, st, ka)
+#define SKINNY_ROW(nl)                                 \
+  switch (NW) {                                        \
+    case 1: SKINNY_LAUNCH(nl, 1); break;               \
+    case 2: SKINNY_LAUNCH(nl, 2); break;               \
+    case 3: SKINNY_LAUNCH(nl, 3); break;               \
+    default: SKINNY_LAUNCH(nl, 4); break;              \
+  }
+      switch (NL) {
+        case 1: SKINNY_ROW(1); break;
+        case 2: SKINNY_ROW(2); break;
+        case 3: SKINNY_ROW(3); break;
+        default: SKINNY_ROW(4); break;
+      }
+#undef SKINNY_ROW
 #undef SKINNY_LAUNCH
-      HIP_TRY(e, rc);
+      HIP_TRY(e, hipGetLastError());
       s.skinny_launched = true;
     }
     s.i_next = s.i_next > count ? s.i_next - count : 0;
