@@ -1,7 +1,7 @@
 """numpy restatement of the engine's counter-based RNG (sdrm_amd/csrc/philox.h) — TEST INFRASTRUCTURE.
 
 Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the Random123
-reference constants), counter = (global row, column pair, purpose | sub-step << 8, step or call id),
+reference constants), counter = (global row, column quad (pair for the forward-only mask), purpose | sub-step << 8, step or call id),
 key = the 64-bit seed.  This is NOT a restatement of anything in the reference (which uses torch's
 default generators); it exists so that PHILOX-mode runs of the HIP engine can be
 replayed through the oracle with explicit randoms.  Integer outputs (t, keep masks, Tj) must match the
@@ -81,19 +81,37 @@ def forward_keep(seed, step, row0, n, L):
     return _interleave((z & np.uint64(1)).astype(np.uint8), ((z >> np.uint64(8)) & np.uint64(1)).astype(np.uint8), L)
 
 
+def _quads(row0, n, L):
+    rows = (np.arange(n, dtype=np.uint64) + np.uint64(row0))[:, None]
+    quads = np.arange((L + 3) // 4, dtype=np.uint64)[None, :]
+    return rows, quads
+
+
+def _quad_normals(words, L):
+    n0, n1 = box_muller(words[0], words[1])
+    n2, n3 = box_muller(words[2], words[3])
+    out = np.empty((n0.shape[0], 4 * n0.shape[1]), dtype=np.float32)
+    out[:, 0::4], out[:, 1::4], out[:, 2::4], out[:, 3::4] = n0, n1, n2, n3
+    return out[:, :L]
+
+
 def sample_randoms(seed, call_id, row0, n, L, T, nd, multires):
     """xT [n,L], z [T+1,n,L] (already * nd, z[0]=z[1]=0), keep [T+1,n,L], Tj [n] (or None) — what
-    k_sample_init / k_reverse_update draw.  keep[i] rides on the Philox call of sub-step i+1."""
-    rows, pairs = _grid(row0, n, L)
-    x, y, _, _ = philox4x32_10(rows, pairs, PURPOSE_SAMPLE_XT, call_id, seed)
-    xT = _interleave(*box_muller(x, y), L)
+    k_sample_init / k_reverse_update / the fused reverse epilogue / k_skinny_sample draw: one Philox call per group of
+    four columns (counter = column quad): (x, y) and (z, w) are two Box-Muller pairs (bits 8..31 of each word), bit 0
+    of word j is the keep bit of column j.  keep[i] rides on the call of sub-step i+1."""
+    rows, quads = _quads(row0, n, L)
+    xT = _quad_normals(philox4x32_10(rows, quads, PURPOSE_SAMPLE_XT, call_id, seed), L)
     z = np.zeros((T + 1, n, L), np.float32)
     keep = np.zeros((T + 1, n, L), np.uint8)
     for sub in range(2, T + 2):
-        x, y, zz, _ = philox4x32_10(rows, pairs, PURPOSE_SAMPLE_STEP | (sub << 8), call_id, seed)
+        words = philox4x32_10(rows, quads, PURPOSE_SAMPLE_STEP | (sub << 8), call_id, seed)
         if sub <= T:
-            z[sub] = _interleave(*box_muller(x, y), L) * np.float32(nd)
-        keep[sub - 1] = _interleave((zz & np.uint64(1)).astype(np.uint8), ((zz >> np.uint64(8)) & np.uint64(1)).astype(np.uint8), L)
+            z[sub] = _quad_normals(words, L) * np.float32(nd)
+        kq = np.empty((n, 4 * quads.shape[1]), dtype=np.uint8)
+        for j in range(4):
+            kq[:, j::4] = (words[j] & np.uint64(1)).astype(np.uint8)
+        keep[sub - 1] = kq[:, :L]
     Tj = None
     if multires:
         tx, _, _, _ = philox4x32_10(rows[:, 0], 0, PURPOSE_SAMPLE_TJ, call_id, seed)

@@ -571,47 +571,48 @@ struct SampleInitArgs {
 
 __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
   const int s = blockIdx.y;
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  const int c = 2 * q;
+  const int q = blockIdx.x * 256 + threadIdx.x;   // column quad: one Philox call, 16-byte stores
+  const int c = 4 * q;
   if (c >= a.LP || s >= a.MP) return;
-  float x[2] = {0.f, 0.f}, u[2] = {0.f, 0.f};
+  float x[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
   if (s < a.n) {
     const int r = a.rowid ? a.rowid[s] : s;
     const int first = a.Tj ? (int)a.Tj[s] : a.T;   // the step this row starts at
     if (c < a.L) {
-      uint32_t bits = 0;
-      float nrm[2] = {0.f, 0.f};
+      uint32_t bits[4] = {0u, 0u, 0u, 0u};
+      float nrm[4] = {0.f, 0.f, 0.f, 0.f};
       if (a.mode != 0) {
         const uint32_t grow = (uint32_t)(a.row0 + r);
         const U4 w = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_XT, a.call_id, a.seed_lo, a.seed_hi);
         box_muller(w.x, w.y, nrm[0], nrm[1]);
+        box_muller(w.z, w.w, nrm[2], nrm[3]);
         // the keep bits of step i ride on the Philox call that draws z_{i+1} (see k_reverse_update)
         const U4 w2 = philox4x32_10(grow, (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)(first + 1) << 8), a.call_id,
                                     a.seed_lo, a.seed_hi);
-        bits = w2.z;
+        bits[0] = w2.x; bits[1] = w2.y; bits[2] = w2.z; bits[3] = w2.w;
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const int cc = c + j;
         if (cc < a.L) {
           const size_t idx = (size_t)r * a.L + cc;
           x[j] = (a.mode == 0) ? a.xT[idx] : nrm[j];
-          const bool k = (a.mode == 0) ? (a.keep[(size_t)first * a.n * a.L + idx] != 0) : (((bits >> (8 * j)) & 1u) != 0);
+          const bool k = (a.mode == 0) ? (a.keep[(size_t)first * a.n * a.L + idx] != 0) : ((bits[j] & 1u) != 0);
           u[j] = k ? 2.f * x[j] : 0.f;
         }
       }
     }
   }
-  *reinterpret_cast<float2*>(a.X + (size_t)s * a.LP + c) = make_float2(x[0], x[1]);
-  *reinterpret_cast<float2*>(a.U + (size_t)s * a.K0 + c) = make_float2(u[0], u[1]);
+  *reinterpret_cast<float4*>(a.X + (size_t)s * a.LP + c) = make_float4(x[0], x[1], x[2], x[3]);
+  *reinterpret_cast<float4*>(a.U + (size_t)s * a.K0 + c) = make_float4(u[0], u[1], u[2], u[3]);
 }
 
 // One DDPM reverse update on the sampler's padded state (denoise_add_noise, train_SDRM.py:20-25) fused
 // with the next step's input dropout (F.dropout, :100):
 //   x <- (x - eps_hat*c1)/sqrt(alpha_i) + sqrt(beta_i)*z   for rows with Tj >= i (all rows if Tj == null)
 //   U_next = 2*keep_{i-1}*x
-// One thread per column pair: in PHILOX mode one Philox call yields the pair's two normals z_i and the
-// pair's keep bits for step i-1.
+// One thread per column quad: in PHILOX mode one Philox call yields the quad's four normals z_i and its four
+// keep bits for step i-1.
 struct ReverseArgs {
   float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj; const int* rowid;
   int s0, n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
@@ -621,19 +622,20 @@ struct ReverseArgs {
 __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
   const int s = a.s0 + blockIdx.y;               // slot; this launch covers the active slots [s0, n) of one row chain
   const int q = blockIdx.x * 256 + threadIdx.x;
-  const int c = 2 * q;
+  const int c = 4 * q;
   if (c >= a.L || s >= a.n) return;
   const int r = a.rowid ? a.rowid[s] : s;       // original row: indexes explicit randoms and keys Philox
   const size_t xi = (size_t)s * a.LP + c;
-  const float2 xo = *reinterpret_cast<const float2*>(a.X + xi);
-  const float2 e = *reinterpret_cast<const float2*>(a.Y + xi);
+  const float4 xo4 = *reinterpret_cast<const float4*>(a.X + xi);
+  const float4 e4 = *reinterpret_cast<const float4*>(a.Y + xi);
+  const float xo[4] = {xo4.x, xo4.y, xo4.z, xo4.w}, e[4] = {e4.x, e4.y, e4.z, e4.w};
   const bool active = (a.Tj == nullptr) || (a.Tj[s] >= (int64_t)a.step_i);
-  float z[2] = {0.f, 0.f};
-  bool kp[2] = {false, false};
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  bool kp[4] = {false, false, false, false};
   if (a.step_i > 1) {
     if (a.mode == 0) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 4; ++j)
         if (c + j < a.L) {
           const size_t idx = (size_t)r * a.L + c + j;
           z[j] = a.Z[idx];
@@ -643,16 +645,20 @@ __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
       const U4 w = philox4x32_10((uint32_t)(a.row0 + r), (uint32_t)q, PURPOSE_SAMPLE_STEP | ((uint32_t)a.step_i << 8),
                                  a.call_id, a.seed_lo, a.seed_hi);
       box_muller(w.x, w.y, z[0], z[1]);
-      z[0] *= a.nd; z[1] *= a.nd;
-      kp[0] = w.z & 1u; kp[1] = (w.z >> 8) & 1u;
+      box_muller(w.z, w.w, z[2], z[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) z[j] *= a.nd;
+      kp[0] = w.x & 1u; kp[1] = w.y & 1u; kp[2] = w.z & 1u; kp[3] = w.w & 1u;
     }
   }
-  float xn[2];
-  xn[0] = active ? (xo.x - e.x * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[0] : xo.x;
-  xn[1] = (c + 1 < a.L) ? (active ? (xo.y - e.y * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[1] : xo.y) : 0.f;
-  *reinterpret_cast<float2*>(a.X + xi) = make_float2(xn[0], xn[1]);
+  float xn[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    xn[j] = (c + j < a.L) ? (active ? (xo[j] - e[j] * a.c1) / a.sqrt_alpha + a.sqrt_beta * z[j] : xo[j]) : 0.f;
+  *reinterpret_cast<float4*>(a.X + xi) = make_float4(xn[0], xn[1], xn[2], xn[3]);
   if (a.step_i > 1)
-    *reinterpret_cast<float2*>(a.U + (size_t)s * a.K0 + c) = make_float2(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f);
+    *reinterpret_cast<float4*>(a.U + (size_t)s * a.K0 + c) =
+        make_float4(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f, kp[2] ? 2.f * xn[2] : 0.f, kp[3] ? 2.f * xn[3] : 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L, const int* rowid) {

@@ -210,6 +210,17 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 }
 
 // The work-group body; `bid` is the work-group's index inside ITS problem (== blockIdx.x for a plain launch).
+// value of lane (l ^ 1) / (l ^ 2) of the same quad (DPP quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E), and of quad lane K
+template <int CTRL>
+__device__ __forceinline__ float quad_xor(float v) {
+  const int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, CTRL, 0xF, 0xF, true));
+}
+template <int K>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, K * 0x55, 0xF, 0xF, true);
+}
+
 template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN, MF = Cfg::MF;
@@ -543,38 +554,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = y[r];
       } else if (EPI == EPI_TANH_REV) {
         // x <- (x - eps_hat*c1)/sqrt(alpha_i) + sqrt(beta_i)*z ; U_next = keep ? 2x : 0   (train_SDRM.py:20-25 + :100),
-        // the arithmetic of k_reverse_update.  One Philox call serves a column PAIR (two normals, two keep bits): the
-        // even-column lane draws for the first half of its rows, its odd-column neighbour for the second half, and
-        // they swap through the wave (lane ^ 1) - one call per pair, as in the stand-alone kernel.
-        constexpr int HALF = NR / 2;
-        const bool odd = col & 1;
+        // the arithmetic of k_reverse_update.  One Philox call serves a column QUAD (four normals, four keep bits), as
+        // in the stand-alone kernel: the four lanes of a quad each draw for a quarter of the tile's rows, then a 4x4
+        // transpose across the quad (two DPP butterfly stages) hands every lane the normals of its own column.
+        constexpr int Q = NR / 4;
+        const int kq = col & 3;
+        const bool k0 = kq & 1, k1 = kq & 2;
         const bool noise = p.rev_step > 1;
-        float zlo[HALF], zhi[HALF];
-        uint32_t blo[HALF], bhi[HALF];
+        float zq[Q][4];
+        uint32_t kb[Q];   // bit kk: keep bit of row kk*Q + h, my column
 #pragma unroll
-        for (int h = 0; h < HALF; ++h) {
-          float n0 = 0.f, n1 = 0.f;
+        for (int h = 0; h < Q; ++h) {
+          float n[4] = {0.f, 0.f, 0.f, 0.f};
           uint32_t bits = 0u;
           if (noise) {
-            const int slot = p.rev_s0 + rbase + rowoff(odd ? HALF + h : h);
-            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 1),
+            const int slot = p.rev_s0 + rbase + (MF == 32 ? 8 * kq + h : kq);   // rowoff(kq * Q + h)
+            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 2),
                                        PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);
-            box_muller(w.x, w.y, n0, n1);
-            n0 *= p.rev_nd; n1 *= p.rev_nd;
-            bits = w.z;
+            box_muller(w.x, w.y, n[0], n[1]);
+            box_muller(w.z, w.w, n[2], n[3]);
+            bits = (w.x & 1u) | ((w.y & 1u) << 1) | ((w.z & 1u) << 2) | ((w.w & 1u) << 3);
           }
-          const float mine = odd ? n1 : n0, theirs = odd ? n0 : n1;     // my column's normal / my neighbour's
-          const float got = __shfl_xor(theirs, 1, 64);                   // the neighbour drew my normal for ITS rows
-          const uint32_t gotb = (uint32_t)__shfl_xor((int)bits, 1, 64);
-          zlo[h] = odd ? got : mine;  blo[h] = odd ? gotb : bits;        // rows h         (drawn by the even lane)
-          zhi[h] = odd ? mine : got;  bhi[h] = odd ? bits : gotb;        // rows HALF + h  (drawn by the odd lane)
+          float g;
+          g = quad_xor<0xB1>(k0 ? n[0] : n[1]); if (k0) n[0] = g; else n[1] = g;
+          g = quad_xor<0xB1>(k0 ? n[2] : n[3]); if (k0) n[2] = g; else n[3] = g;
+          g = quad_xor<0x4E>(k1 ? n[0] : n[2]); if (k1) n[0] = g; else n[2] = g;
+          g = quad_xor<0x4E>(k1 ? n[1] : n[3]); if (k1) n[1] = g; else n[3] = g;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) zq[h][kk] = n[kk] * p.rev_nd;   // now: lane kk's draw for MY column
+          kb[h] = ((quad_bcast<0>(bits) >> kq) & 1u) | (((quad_bcast<1>(bits) >> kq) & 1u) << 1) |
+                  (((quad_bcast<2>(bits) >> kq) & 1u) << 2) | (((quad_bcast<3>(bits) >> kq) & 1u) << 3);
         }
-        const int sh = odd ? 8 : 0;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int row = rbase + rowoff(r);
-          const float z = r < HALF ? zlo[r % HALF] : zhi[r % HALF];
-          const bool kp = ((r < HALF ? blo[r % HALF] : bhi[r % HALF]) >> sh) & 1u;
+          const float z = zq[r % Q][r / Q];
+          const bool kp = (kb[r % Q] >> (r / Q)) & 1u;
           if (row + p.rev_s0 < p.rev_n) {
             const size_t xi = (size_t)(p.rev_s0 + row) * p.rev_ldx + col;
             const float e = tanh_fast(acc[a][b][r] + bias);

@@ -1,5 +1,5 @@
 // Counter-based RNG for the PHILOX mode: Philox4x32-10 keyed by the 64-bit
-// seed, counter = (global row, column pair, purpose | sub-step << 8, step).  Keying by the GLOBAL
+// seed, counter = (global row, column quad, purpose | sub-step << 8, step).  Keying by the GLOBAL
 // row makes a G-GPU run draw exactly the randoms of the 1-GPU run.  The same function is restated
 // in numpy in oracle/philox_ref.py so PHILOX-mode runs are parity-testable too.
 #pragma once
@@ -9,12 +9,12 @@
 namespace sdrm {
 
 enum : uint32_t {
-  PURPOSE_TRAIN_ELEM = 1,  // noise pair + 3x2 dropout bits of one train step
+  PURPOSE_TRAIN_ELEM = 1,  // four normals + 3x4 dropout bits of one train step (column quad)
   PURPOSE_TRAIN_T = 2,     // timestep of a row
-  PURPOSE_SAMPLE_XT = 3,   // start noise pair
-  PURPOSE_SAMPLE_STEP = 4, // (z pair, dropout bits) of reverse step i (i in bits 8..)
+  PURPOSE_SAMPLE_XT = 3,   // start noise of a column quad
+  PURPOSE_SAMPLE_STEP = 4, // (four z, four dropout bits) of reverse step i (i in bits 8..), column quad
   PURPOSE_SAMPLE_TJ = 5,   // multi-resolution start step of a row
-  PURPOSE_FORWARD = 6      // dropout bits of a plain forward call
+  PURPOSE_FORWARD = 6      // dropout bits of a plain forward call (column pair)
 };
 
 struct U4 { uint32_t x, y, z, w; };

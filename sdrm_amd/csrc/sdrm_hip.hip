@@ -1149,7 +1149,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   ia.X = e->X; ia.U = e->Us; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->LP; ia.MP = MP; ia.T = T;
   ia.mode = mode; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
-  dim3 grid((e->LP / 2 + 255) / 256, MP);
+  dim3 grid((e->LP / 4 + 255) / 256, MP);
   hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
   HIP_TRY(e, hipGetLastError());
   e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, false, false, i_start};
@@ -1253,7 +1253,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ra.c1 = c1; ra.sqrt_alpha = sqrt_alpha; ra.sqrt_beta = sqrt_beta;
       ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
       ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
-      hipLaunchKernelGGL(k_reverse_update, dim3((L / 2 + 256) / 256, rows), dim3(256), 0, sc, ra);
+      hipLaunchKernelGGL(k_reverse_update, dim3(((L + 3) / 4 + 255) / 256, rows), dim3(256), 0, sc, ra);
       HIP_TRY(e, hipGetLastError());
     }
   }

@@ -14,7 +14,7 @@
 //     loop (same k permutation),
 //     C layout -> A layout of the next layer through two alternating LDS tiles, one barrier per layer,
 //     epilogue of the last layer = tanh, DDPM reverse update (denoise_add_noise, :20-25) and the next step's
-//     input dropout (F.dropout, :100), with z / keep bits from Philox (one call per row and column pair, dealt to
+//     input dropout (F.dropout, :100), with z / keep bits from Philox (one call per row and column quad, dealt to
 //     all lanes of the work-group at the top of the step and passed through LDS) or from caller arrays.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(64 * (NL > NW ? NL : NW)) void k_skinny_sample(cons
   constexpr int LP = 16 * NL, WP = 16 * NW, NV = NL > NW ? NL : NW;
   constexpr int SCR = (LP > WP ? LP : WP) + 4;
   __shared__ __attribute__((aligned(16))) float tile[2][16 * SCR];
-  __shared__ float zbuf[16 * LP];      // the step's normals, [row][col]
-  __shared__ uint8_t kbuf[16 * LP];    // keep bits of the step below
+  __shared__ __attribute__((aligned(16))) float zbuf[16 * LP];      // the step's normals, [row][col]
+  __shared__ __attribute__((aligned(4))) uint8_t kbuf[16 * LP];    // keep bits of the step below
   __shared__ int rid[16];              // global row id of each slot (Philox counter)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -122,11 +122,11 @@ __global__ __launch_bounds__(64 * (NL > NW ? NL : NW)) void k_skinny_sample(cons
   for (int off = 32; off > 0; off >>= 1) ihi = max(ihi, __shfl_xor(ihi, off, 64));
   ihi = __builtin_amdgcn_readfirstlane(ihi);
 
-  // PHILOX randoms of a step: one call per (row, column pair) gives the pair's two normals and the keep bits of the
+  // PHILOX randoms of a step: one call per (row, column quad) gives the quad's four normals and the keep bits of the
   // step below.  The calls of a 16-row block are dealt to ALL lanes of the work-group (a call is ~1000 cycles of
-  // integer multiplies: left to the three waves that own latent tiles it doubled the step), results go through
-  // LDS in the [row][col] layout the epilogue reads.  Purpose word: x_T, or (step << 8 | SAMPLE_STEP).
-  const int P = (a.L + 1) >> 1, ncall = 16 * P, nthr = 64 * NV;
+  // integer multiplies: left to the waves that own latent tiles it doubled the step), results go through LDS in
+  // the [row][col] layout the epilogue reads.  Purpose word: x_T, or (step << 8 | SAMPLE_STEP).
+  const int P = (a.L + 3) >> 2, ncall = 16 * P, nthr = 64 * NV;
   auto produce = [&](uint32_t purpose) {
     for (int f0 = 0; f0 < ncall; f0 += nthr) {
       // the last, partial round goes to the highest lanes (the wave without a latent tile, if there is one)
@@ -135,12 +135,12 @@ __global__ __launch_bounds__(64 * (NL > NW ? NL : NW)) void k_skinny_sample(cons
       if (f >= f0) {
         const int r = f / P, pr = f - r * P;
         const U4 w = philox4x32_10((uint32_t)(a.row0 + rid[r]), (uint32_t)pr, purpose, a.call_id, a.seed_lo, a.seed_hi);
+        f32x4 nn;
         float n0, n1;
-        box_muller(w.x, w.y, n0, n1);
-        zbuf[r * LP + 2 * pr] = n0;
-        zbuf[r * LP + 2 * pr + 1] = n1;
-        kbuf[r * LP + 2 * pr] = (uint8_t)(w.z & 1u);
-        kbuf[r * LP + 2 * pr + 1] = (uint8_t)((w.z >> 8) & 1u);
+        box_muller(w.x, w.y, n0, n1); nn[0] = n0; nn[1] = n1;
+        box_muller(w.z, w.w, n0, n1); nn[2] = n0; nn[3] = n1;
+        *reinterpret_cast<f32x4*>(&zbuf[r * LP + 4 * pr]) = nn;
+        *reinterpret_cast<uint32_t*>(&kbuf[r * LP + 4 * pr]) = (w.x & 1u) | ((w.y & 1u) << 8) | ((w.z & 1u) << 16) | ((w.w & 1u) << 24);
       }
     }
   };
