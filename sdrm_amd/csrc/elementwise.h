@@ -405,15 +405,44 @@ struct EmbBwdArgs {
   int L, W, T;
 };
 
-// Blocks [0, T]: dE row t (1024 threads = 16 w-slices x 64 j-lanes; the slices meet in LDS).
-// Blocks beyond: the independent product dW0[:, L:] = dC0^T * E, 1024 outputs per block.
+// sum over t in [lane, n) step 4 of x[t*sx] * y[t*sy]: a quarter of a dot product per lane of a quad, NB elements per
+// batch all in flight at once (one memory round trip per batch), then the quarters meet through the wave.
+template <int NB>
+__device__ __forceinline__ float dot_quad(const float* __restrict__ x, int sx, const float* __restrict__ y, int sy, int n,
+                                          int lane4) {
+  float s0 = 0.f, s1 = 0.f;
+  for (int t0 = lane4; t0 < n; t0 += 4 * NB) {
+    float xv[NB], yv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int t = t0 + 4 * u;
+      const bool in = t < n;
+      xv[u] = in ? x[(unsigned)t * (unsigned)sx] : 0.f;
+      yv[u] = in ? y[(unsigned)t * (unsigned)sy] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u += 2) {
+      s0 = fmaf(xv[u], yv[u], s0);
+      if (u + 1 < NB) s1 = fmaf(xv[u + 1], yv[u + 1], s1);
+    }
+  }
+  float s = s0 + s1;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  return s;
+}
+
+// Blocks [0, T]: dE row t (1024 threads = 16 w-slices x 64 j-lanes, every lane carries columns j and j + 64 at once; the
+// slices meet in LDS).  Blocks beyond: the independent product dW0[:, L:] = dC0^T * E, 256 outputs per block, four
+// lanes per output.  These kernels are latency chains: what counts is the number of dependent memory round trips.
 __global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
-  __shared__ float red[16][64];
+  __shared__ float red[16][128];
   if ((int)blockIdx.x > a.T) {
-    const int i = ((int)blockIdx.x - a.T - 1) * 1024 + threadIdx.x;
-    if (i < a.W * a.T) {
+    const int i = ((int)blockIdx.x - a.T - 1) * 256 + (threadIdx.x >> 2);
+    if (i < a.W * a.T) {   // quad-uniform
       const int w = i / a.T, j = i - w * a.T;
-      a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = dot_strided(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, a.T + 1);
+      const float s = dot_quad<20>(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, a.T + 1, threadIdx.x & 3);
+      if ((threadIdx.x & 3) == 0) a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = s;
     }
     return;
   }
@@ -421,42 +450,61 @@ __global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
   const int jj = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int ldw = a.L + a.T;
   const int wlo = (a.W * part) / 16, whi = (a.W * (part + 1)) / 16;
-  for (int j0 = 0; j0 < a.T; j0 += 64) {
-    const int j = j0 + jj;
-    float s0 = 0.f;
-    if (j < a.T)
-      s0 = dot_strided(a.dC0T + (size_t)wlo * a.TP + t, a.TP, a.W0 + (size_t)wlo * ldw + a.L + j, ldw, whi - wlo);
+  for (int j0 = 0; j0 < a.T; j0 += 128) {
+    const int j = j0 + jj, j2 = j + 64;
+    const bool in1 = j < a.T, in2 = j2 < a.T;
+    float s1 = 0.f, s2 = 0.f;
+    constexpr int NB = 16;   // 48 loads in flight (a 1024-thread block has 128 VGPRs per lane)
+    for (int w0 = wlo; w0 < whi; w0 += NB) {
+      float dv[NB], y1[NB], y2[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int w = w0 + u;
+        const bool in = w < whi;
+        const unsigned od = (unsigned)w * (unsigned)a.TP + (unsigned)t;          // 32-bit offsets from uniform bases:
+        const unsigned ow = (unsigned)w * (unsigned)ldw + (unsigned)(a.L + j);   // half the address registers
+        dv[u] = in ? a.dC0T[od] : 0.f;
+        y1[u] = (in && in1) ? a.W0[ow] : 0.f;
+        y2[u] = (in && in2) ? a.W0[ow + 64u] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) { s1 = fmaf(dv[u], y1[u], s1); s2 = fmaf(dv[u], y2[u], s2); }
+    }
     __syncthreads();
-    red[part][jj] = s0;
+    red[part][jj] = s1;
+    red[part][jj + 64] = s2;
     __syncthreads();
-    if (part == 0 && j < a.T) {
+    if (threadIdx.x < 128 && j0 + (int)threadIdx.x < a.T) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) s += red[q][jj];
-      a.dE[(size_t)t * a.T + j] = s;
+      for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
+      a.dE[(size_t)t * a.T + j0 + threadIdx.x] = s;
     }
   }
 }
 
+// four lanes per output: dWe (T*T outputs), then dbe (T outputs)
 __global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
-  const int n1 = 0, n2 = a.T * a.T, n3 = a.T;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n2 = a.T * a.T, n3 = a.T;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, l4 = threadIdx.x & 3;
   const int nt = a.T + 1;
-  if (i < n1 + n2) {
-    const int k = i - n1;
-    const int j = k / a.T, ii = k - j * a.T;
-    a.g[a.off_we + k] = dot_strided(a.dE + j, a.T, a.temb + ii, a.T, nt);
-  } else if (i < n1 + n2 + n3) {
-    const int j = i - n1 - n2;
+  if (i < n2) {
+    const int j = i / a.T, ii = i - j * a.T;
+    const float s = dot_quad<20>(a.dE + j, a.T, a.temb + ii, a.T, nt, l4);
+    if (l4 == 0) a.g[a.off_we + i] = s;
+  } else if (i < n2 + n3) {
+    const int j = i - n2;
     float s = 0.f;
-    for (int t0 = 0; t0 < nt; t0 += 16) {
-      float v[16];
+    for (int t0 = l4; t0 < nt; t0 += 4 * 20) {
+      float v[20];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (t0 + u < nt) ? a.dE[(size_t)(t0 + u) * a.T + j] : 0.f;
+      for (int u = 0; u < 20; ++u) v[u] = (t0 + 4 * u < nt) ? a.dE[(size_t)(t0 + 4 * u) * a.T + j] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
+      for (int u = 0; u < 20; ++u) s += v[u];
     }
-    a.g[a.off_be + j] = s;
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (l4 == 0) a.g[a.off_be + j] = s;
   }
 }
 

@@ -932,10 +932,10 @@ int backward_embedding(sdrm_engine* e, float* gout, hipStream_t st) {
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = gout;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
-  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 1023) / 1024), dim3(1024), 0, st, ea);
+  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 255) / 256), dim3(1024), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
   const int items = e->T * e->T + e->T;
-  hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 255) / 256), dim3(256), 0, st, ea);
+  hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 63) / 64), dim3(256), 0, st, ea);   // four lanes per output
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
