@@ -583,24 +583,55 @@ struct AdamArgs {
   int update;   // 0: only re-pack compute copies from p (set_params)
 };
 
+__device__ __forceinline__ float adam_element(const AdamArgs& a, int64_t fi) {
+  float w = a.p[fi];
+  if (a.update) {
+    const float gg = a.g[fi] + a.wd * w;
+    const float mm = a.b1 * a.m[fi] + (1.f - a.b1) * gg;
+    const float vv = a.b2 * a.v[fi] + (1.f - a.b2) * gg * gg;
+    a.m[fi] = mm; a.v[fi] = vv;
+    const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
+    w = w - a.step_size * (mm / denom);
+    a.p[fi] = w;
+  }
+  return w;
+}
+
+// One grid row (blockIdx.y) per parameter tensor.  Tensors that keep a transposed compute copy go tile by tile
+// (32 x 32 through LDS, so both copies are written along their contiguous index); the rest element by element.
 __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs a) {
   const Job& jb = tab.j[blockIdx.y];
+  if (jb.dstT != nullptr) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int tr = (jb.rows + 31) >> 5, tc = (jb.cols + 31) >> 5;
+    for (int tix = blockIdx.x; tix < tr * tc; tix += gridDim.x) {
+      const int r0 = (tix / tc) * 32, c0 = (tix % tc) * 32;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        float w = 0.f;
+        if (r < jb.rows && c < jb.cols) {
+          w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
+          if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+        }
+        tile[ty + 8 * k][tx] = w;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < jb.rows && c < jb.ncols) jb.dstT[(size_t)c * jb.dstT_ld + r] = tile[tx][ty + 8 * k];
+      }
+      __syncthreads();
+    }
+    return;
+  }
   const int64_t total = (int64_t)jb.rows * jb.cols;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
-    const int64_t fi = jb.flat_off + (int64_t)r * jb.flat_ld + c;
-    float w = a.p[fi];
-    if (a.update) {
-      const float gg = a.g[fi] + a.wd * w;
-      const float mm = a.b1 * a.m[fi] + (1.f - a.b1) * gg;
-      const float vv = a.b2 * a.v[fi] + (1.f - a.b2) * gg * gg;
-      a.m[fi] = mm; a.v[fi] = vv;
-      const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
-      w = w - a.step_size * (mm / denom);
-      a.p[fi] = w;
-    }
+    const float w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
     if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
-    if (jb.dstT != nullptr && c < jb.ncols) jb.dstT[(size_t)c * jb.dstT_ld + r] = w;
   }
 }
 

@@ -376,7 +376,11 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
     a.step_size = (float)((double)lr / bc1);
     a.bc2_sqrt = (float)std::sqrt(bc2);
   }
-  dim3 grid(128, tab.n_adam);
+  // enough work-groups that the largest tensor is one or two passes per thread (a pass is a chain of dependent loads)
+  int64_t biggest = 0;
+  for (int k = 0; k < tab.n_adam; ++k) biggest = std::max<int64_t>(biggest, (int64_t)tab.j[k].rows * tab.j[k].cols);
+  const int gx = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (biggest + 511) / 512));
+  dim3 grid(gx, tab.n_adam);
   hipLaunchKernelGGL(k_adam, grid, dim3(256), 0, st, tab, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
