@@ -323,8 +323,19 @@ void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
   S = want < 1 ? 1 : want;
   if (S > S_MAX) S = S_MAX;
   if (S > max_by_rows) S = max_by_rows;
-  if (S >= 8) S = (S + 4) / 8 * 8;   // K-slices are dealt to the 8 XCDs: keep them balanced
-  if (S > S_MAX) S = S_MAX;
+  // K-slices are dealt to the 8 XCDs (a slice's tiles share one L2): a slice count that is not a multiple of 8 leaves
+  // XCDs idle for a whole round (ML-100k, 6 slices: 419 us per train step against 394 with 8).  Take the nearest
+  // multiple of 8 that the rows allow and that survives the rounding of the chunk length.
+  if (S >= 4 && max_by_rows >= 8) {
+    int s8 = (S + 4) / 8 * 8;
+    if (s8 < 8) s8 = 8;
+    const int cap = std::min(S_MAX, max_by_rows) / 8 * 8;
+    if (s8 > cap) s8 = cap;
+    for (int c = s8; c >= 8; c -= 8) {
+      const int kc = round_up((Mrows + c - 1) / c, BK);
+      if (((Mrows + kc - 1) / kc) % 8 == 0) { S = c; break; }
+    }
+  }
   kchunk = round_up((Mrows + S - 1) / S, BK);
   S = (Mrows + kchunk - 1) / kchunk;
 }
