@@ -316,6 +316,48 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   // column: 352 = 5.5 x 64) issues no LDS reads and no MFMAs; it still loads, stores and meets the
   // barriers.  Its SIMD's matrix pipe goes to the other work-groups resident on the CU.
   const bool wave_active = (m0 + wm * (BM / Cfg::WM) < p.limA) && (n0 + wn * (BN / Cfg::WN) < p.limB);
+  // EPI_TANH_REV: the reverse update's randoms (z_i and the keep bits of step i-1) depend on (row, column, step) only, so
+  // they are drawn BEFORE the main loop, while the prologue's global loads are in flight, and wait in registers; drawn
+  // in the epilogue they sit on the critical path of a launch whose work-groups all finish together (5429 rows: one
+  // round).  One Philox call serves a column QUAD (four normals, four keep bits), as in k_reverse_update: the four
+  // lanes of a quad each draw for a quarter of the tile's rows, then a 4x4 transpose across the quad (two DPP butterfly
+  // stages) hands every lane the normals of its own column.
+  constexpr int RQ = (EPI == EPI_TANH_REV) ? NR / 4 : 1;
+  float rev_z[TM][TN][RQ][4];     // [..][h][kk]: normal (x nd) of row kk*RQ + h of the MFMA tile, this lane's column
+  uint32_t rev_kb[TM][TN][RQ];    // bit kk: keep bit of that row
+  auto rev_draw = [&]() {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + wn * (BN / Cfg::WN) + b * MF + l31;
+        const int rbase = m0 + wm * (BM / Cfg::WM) + a * MF + 4 * lhi;
+        const int kq = col & 3;
+        const bool k0 = kq & 1, k1 = kq & 2;
+#pragma unroll
+        for (int h = 0; h < RQ; ++h) {
+          float n[4] = {0.f, 0.f, 0.f, 0.f};
+          uint32_t bits = 0u;
+          if (p.rev_step > 1) {
+            const int slot = p.rev_s0 + rbase + (MF == 32 ? 8 * kq + h : kq);   // rowoff(kq * RQ + h)
+            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 2),
+                                       PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);
+            box_muller(w.x, w.y, n[0], n[1]);
+            box_muller(w.z, w.w, n[2], n[3]);
+            bits = (w.x & 1u) | ((w.y & 1u) << 1) | ((w.z & 1u) << 2) | ((w.w & 1u) << 3);
+          }
+          float g;
+          g = quad_xor<0xB1>(k0 ? n[0] : n[1]); if (k0) n[0] = g; else n[1] = g;
+          g = quad_xor<0xB1>(k0 ? n[2] : n[3]); if (k0) n[2] = g; else n[3] = g;
+          g = quad_xor<0x4E>(k1 ? n[0] : n[2]); if (k1) n[0] = g; else n[2] = g;
+          g = quad_xor<0x4E>(k1 ? n[1] : n[3]); if (k1) n[1] = g; else n[3] = g;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) rev_z[a][b][h][kk] = n[kk] * p.rev_nd;   // now: lane kk's draw for MY column
+          rev_kb[a][b][h] = ((quad_bcast<0>(bits) >> kq) & 1u) | (((quad_bcast<1>(bits) >> kq) & 1u) << 1) |
+                            (((quad_bcast<2>(bits) >> kq) & 1u) << 2) | (((quad_bcast<3>(bits) >> kq) & 1u) << 3);
+        }
+      }
+  };
   const int aoffk = (wm * (BM / Cfg::WM) + l31) * LDK + ((MF == 32) ? (BK / 2) : 4) * lhi;
   const int boffk = (wn * (BN / Cfg::WN) + l31) * LDK + ((MF == 32) ? (BK / 2) : 4) * lhi;
 
@@ -398,12 +440,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       if constexpr (Cfg::PF == 2) {
         ld(ra0, rb0, 0);
         ld(ra1, rb1, 1);
+        if constexpr (EPI == EPI_TANH_REV) rev_draw();   // VALU work under the first loads' round trip
         st(ra0, rb0, 0);
         ld(ra0, rb0, 2);
         st(ra1, rb1, 1);
         ld(ra1, rb1, 3);
       } else {
         ld(ra0, rb0, 0);
+        if constexpr (EPI == EPI_TANH_REV) rev_draw();
         st(ra0, rb0, 0);
         ld(ra0, rb0, 1);
         st(ra0, rb0, 1);
@@ -554,42 +598,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = y[r];
       } else if (EPI == EPI_TANH_REV) {
         // x <- (x - eps_hat*c1)/sqrt(alpha_i) + sqrt(beta_i)*z ; U_next = keep ? 2x : 0   (train_SDRM.py:20-25 + :100),
-        // the arithmetic of k_reverse_update.  One Philox call serves a column QUAD (four normals, four keep bits), as
-        // in the stand-alone kernel: the four lanes of a quad each draw for a quarter of the tile's rows, then a 4x4
-        // transpose across the quad (two DPP butterfly stages) hands every lane the normals of its own column.
+        // the arithmetic of k_reverse_update, with the randoms rev_draw() left in registers before the main loop.
         constexpr int Q = NR / 4;
-        const int kq = col & 3;
-        const bool k0 = kq & 1, k1 = kq & 2;
         const bool noise = p.rev_step > 1;
-        float zq[Q][4];
-        uint32_t kb[Q];   // bit kk: keep bit of row kk*Q + h, my column
-#pragma unroll
-        for (int h = 0; h < Q; ++h) {
-          float n[4] = {0.f, 0.f, 0.f, 0.f};
-          uint32_t bits = 0u;
-          if (noise) {
-            const int slot = p.rev_s0 + rbase + (MF == 32 ? 8 * kq + h : kq);   // rowoff(kq * Q + h)
-            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 2),
-                                       PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);
-            box_muller(w.x, w.y, n[0], n[1]);
-            box_muller(w.z, w.w, n[2], n[3]);
-            bits = (w.x & 1u) | ((w.y & 1u) << 1) | ((w.z & 1u) << 2) | ((w.w & 1u) << 3);
-          }
-          float g;
-          g = quad_xor<0xB1>(k0 ? n[0] : n[1]); if (k0) n[0] = g; else n[1] = g;
-          g = quad_xor<0xB1>(k0 ? n[2] : n[3]); if (k0) n[2] = g; else n[3] = g;
-          g = quad_xor<0x4E>(k1 ? n[0] : n[2]); if (k1) n[0] = g; else n[2] = g;
-          g = quad_xor<0x4E>(k1 ? n[1] : n[3]); if (k1) n[1] = g; else n[3] = g;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) zq[h][kk] = n[kk] * p.rev_nd;   // now: lane kk's draw for MY column
-          kb[h] = ((quad_bcast<0>(bits) >> kq) & 1u) | (((quad_bcast<1>(bits) >> kq) & 1u) << 1) |
-                  (((quad_bcast<2>(bits) >> kq) & 1u) << 2) | (((quad_bcast<3>(bits) >> kq) & 1u) << 3);
-        }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int row = rbase + rowoff(r);
-          const float z = zq[r % Q][r / Q];
-          const bool kp = (kb[r % Q] >> (r / Q)) & 1u;
+          const float z = rev_z[a][b][r % Q][r / Q];
+          const bool kp = (rev_kb[a][b][r % Q] >> (r / Q)) & 1u;
           if (row + p.rev_s0 < p.rev_n) {
             const size_t xi = (size_t)(p.rev_s0 + row) * p.rev_ldx + col;
             const float e = tanh_fast(acc[a][b][r] + bias);
