@@ -278,6 +278,45 @@ def test_train_step_vs_oracle(engine_cls, dims):
     e.close()
 
 
+@pytest.mark.parametrize("dims", [(40, 40, 93, 5, 850), (24, 56, 11, 3, 37), (64, 17, 8, 0, 5), (33, 48, 20, 1, 129)])
+def test_narrow_net_train_paths_agree(engine_cls, dims):
+    """Nets with widths <= 64 run their train forward and dgrad chain in the fused kernels of csrc/skinny_train.h
+    (EXPLICIT and PHILOX staging); the general per-layer GEMM path must give the same step: P/S/Q, loss, every
+    gradient tensor, the parameters after Adam.  Same arithmetic, different summation order: 2e-5 normwise."""
+    from sdrm_amd import _lib
+    lib = _lib.load()
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=16), H)
+    x0 = synth.synth_latents(B, L, seed=17)
+    eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=18)
+    out = {}
+    try:
+        for path in (1, 0):
+            lib.sdrm_debug_set_skinny(path)
+            for mode in ("explicit", "philox"):
+                e = engine_cls(L, W, T, H, B)
+                e.set_params(init)
+                if mode == "explicit":
+                    e.train_forward(x0, noise=eps, t=t, keep=keep)
+                else:
+                    e.train_forward(x0, seed=77, step=5, nd=0.9, row0=3)
+                loss = float(e.train_backward().cpu())
+                psq = e.train_outputs(B).cpu().numpy()
+                grads = e.get_grads().cpu().numpy()
+                e.adam_step(1e-5)
+                out[(path, mode)] = (loss, psq, grads, e.get_params().cpu().numpy())
+                e.close()
+    finally:
+        lib.sdrm_debug_set_skinny(1)
+    for mode in ("explicit", "philox"):
+        (l1, p1, g1, w1), (l0, p0, g0, w0) = out[(1, mode)], out[(0, mode)]
+        assert abs(l1 - l0) <= 2e-5 * abs(l0), (mode, l1, l0)
+        assert close(p1, p0, 2e-5), (mode, rel_max(p1, p0))
+        for (n, a), (_, b) in zip(per_tensor(g1, dims[:4]), per_tensor(g0, dims[:4])):
+            assert rel_l2(a, b) <= 2e-5 and rel_max(a, b) <= 2e-5, (mode, n, rel_l2(a, b), rel_max(a, b))
+        assert rel_l2(w1, w0) <= TOL, mode   # Adam's first step is lr*sign(g): a sign flip of a ~0 gradient moves a weight by 2*lr
+
+
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (41, 40, 93, 5, 50), (24, 24, 9, 2, 7)])
 def test_philox_mode_train(engine_cls, dims):
     """PHILOX mode == EXPLICIT mode fed with the numpy restatement of the device generator: integer
