@@ -767,7 +767,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     if (rc) return rc;
     LossArgs la{};
     la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
-    hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(256), 0, st, la);
+    hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
     HIP_TRY(e, hipGetLastError());
     if (!e->fold_sums) {
       hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
@@ -811,7 +811,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   }
   LossArgs la{};
   la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
-  hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(256), 0, st, la);
+  hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
   HIP_TRY(e, hipGetLastError());
   if (!e->fold_sums) {
     hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
