@@ -532,14 +532,28 @@ struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
 __global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab) {
   const Job& jb = tab.j[blockIdx.y];
   if (jb.src == nullptr) return;
-  if (jb.inner > 1) {   // scalar job (slope partials): one wave, fixed order
-    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  if (jb.inner > 1) {   // scalar job (slope partials): one work-group, fixed order
+    if (blockIdx.x != 0) return;
+    // thousands of partials (one per dgrad work-group): every thread takes a batch of 16 with all loads in flight at
+    // once - a thread-serial loop here was a chain of dependent round trips longer than the rest of the kernel
+    __shared__ float red[4];
     float a = 0.f;
     const int total = jb.nslabs * jb.inner;
-    for (int i = threadIdx.x; i < total; i += 64) a += jb.src[(size_t)(i / jb.inner) * jb.slab_stride + (i % jb.inner)];
+    for (int i0 = 0; i0 < total; i0 += 256 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u * 256 + (int)threadIdx.x;
+        v[u] = i < total ? jb.src[(size_t)(i / jb.inner) * jb.slab_stride + (i % jb.inner)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a += v[u];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    if (threadIdx.x == 0) jb.gdst[0] = a;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) jb.gdst[0] = (red[0] + red[1]) + (red[2] + red[3]);
     return;
   }
   const int qpr = (jb.ncols + 3) >> 2;                      // column quads per row
