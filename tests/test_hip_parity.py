@@ -243,7 +243,8 @@ def engine_branch_masks(e, o, caches, B, kink_tol=2e-5):
 
 
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (40, 40, 93, 5, 850), (830, 830, 83, 2, 550),
-                                  (50, 70, 5, 0, 33), (100, 100, 198, 3, 129), (340, 340, 78, 1, 2048)])
+                                  (50, 70, 5, 0, 33), (100, 100, 198, 3, 129), (340, 340, 78, 1, 2048),
+                                  (96, 96, 5, 1, 45000)])   # 135 000 stacked rows: > 4096 slope partials per application
 def test_train_step_vs_oracle(engine_cls, dims):
     """Full tensors (not checksums) against the CPU oracle at sizes it finishes in seconds.  The oracle
     backward is evaluated with the engine's own PReLU branch choice (verified to differ only at
