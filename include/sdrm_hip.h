@@ -215,6 +215,11 @@ int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const i
                       const int32_t* ks_host, int nk, const double* tp, const double* idcg, double* recall, double* ndcg,
                       void* stream);
 
+/* Host-side planning of one split-K weight-gradient launch, exposed for tests (no device work): for a reduction over
+ * `rows` stacked rows into an [n_out, k_in] gradient, the number of K-slices (slabs) and the rows per slice the engine
+ * would use.  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows, slices <= 64, and slices
+ * is a multiple of 8 whenever the rows allow eight slices of at least 128 rows (slices are pinned to the 8 XCDs). */
+int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice);
 /* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
  * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
 int sdrm_debug_set_skinny(int on);

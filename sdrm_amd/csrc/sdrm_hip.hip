@@ -557,6 +557,12 @@ int sdrm_debug_set_skinny(int on) {
   return SDRM_OK;
 }
 
+int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice) {
+  if (!slices || !rows_per_slice || rows < 1 || n_out < 1 || k_in < 1) return SDRM_ERR_ARG;
+  pick_splits(rows, n_out, k_in, *slices, *rows_per_slice);
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_fused_reverse(int mode) {
   g_fuse_rev = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return SDRM_OK;

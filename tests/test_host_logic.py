@@ -34,6 +34,25 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.sdrm_destroy(None) == -1
 
 
+@pytest.mark.parametrize("rows,n_out,k_in", [(24576, 352, 448), (24576, 352, 352), (1664, 832, 928), (1664, 832, 832),
+                                             (2560, 64, 160), (512, 352, 352), (3072, 352, 352), (12288, 352, 352),
+                                             (64, 32, 32), (135040, 96, 96), (192, 4096, 4096)])
+def test_wgrad_split_plan(rows, n_out, k_in):
+    """Split-K planning of a weight-gradient launch (host logic only): the slices cover the rows, are whole K-steps,
+    and come in multiples of 8 (one per XCD) whenever eight slices of >= 128 rows exist and the output is small
+    enough to want at least four."""
+    lib = _lib.load()
+    s, kc = ctypes.c_int(), ctypes.c_int()
+    assert lib.sdrm_debug_plan_wgrad(rows, n_out, k_in, ctypes.byref(s), ctypes.byref(kc)) == 0
+    S, KC = s.value, kc.value
+    assert 1 <= S <= 64 and KC % 32 == 0 and KC >= 32
+    assert S * KC >= rows and (S - 1) * KC < rows                 # covers the rows, no empty slice
+    tiles = -(-n_out // 64) * -(-k_in // 64)
+    if rows // 128 >= 8 and 1024 // tiles >= 4:
+        assert S % 8 == 0, (S, KC)
+    assert lib.sdrm_debug_plan_wgrad(0, 8, 8, ctypes.byref(s), ctypes.byref(kc)) == -1
+
+
 @pytest.mark.parametrize("H", [0, 1, 2, 5])
 def test_parameter_layout_matches_reference(golden, H):
     g = golden("host")
