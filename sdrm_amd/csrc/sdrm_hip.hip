@@ -166,7 +166,13 @@ int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
   return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
 }
 
-int g_nt32_max_rows = 4096;   // NT launches of at most this many rows use the 32x32 tile (SDRM_NT32_MAX_ROWS env: tuning aid)
+int g_nt32_max_rows = 4096;   // sampling / plain-forward NT launches of at most this many rows use the 32x32 tile
+                              // (SDRM_NT32_MAX_ROWS env: tuning aid)
+int g_nt32_max_rows_train = 8192;   // the same for the train step's launches (stacked rows = 3 x batch): 6144 stacked rows
+                                    // (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile, 12288 a tie;
+                                    // the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
+                                    // (SDRM_NT32_MAX_ROWS_TRAIN env)
+int g_nt32_cur = 4096;        // the threshold in force: set by the entry point that is about to launch
 
 // Tile for an unsplit (NT) launch.  With the k-minor LDS image and ds_read_b128 fragments the 32x32x32 tile on the
 // 16-wide MFMA has no ragged tile (352 = 11 x 32), four times the work-groups and a quarter of the dependent MFMA
@@ -179,7 +185,7 @@ int g_nt32_max_rows = 4096;   // NT launches of at most this many rows use the 3
 // train step against 618.)
 int choose_cfg(int M, int N, int K) {
   int cfg = pick_cfg(M, N, K);
-  if (cfg == 0 && g_force_cfg < 0 && M <= g_nt32_max_rows) cfg = 4;
+  if (cfg == 0 && g_force_cfg < 0 && M <= g_nt32_cur) cfg = 4;
   return cfg;
 }
 
@@ -597,6 +603,8 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
   if (const char* env = std::getenv("SDRM_FUSE_REV")) g_fuse_rev = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) g_nt32_max_rows = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) g_nt32_max_rows_train = std::atoi(env);
+  g_nt32_cur = g_nt32_max_rows;
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) g_wgrad_blocks = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
@@ -751,6 +759,7 @@ int sdrm_adam_reset(sdrm_engine* e, void* stream) {
 int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd,
                        uint64_t seed, uint64_t step, float nd, double* sums, void* stream) {
   if (!e || !x0) return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: null pointer");
+  g_nt32_cur = g_nt32_max_rows_train;
   if (B < 1 || B > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_train_forward: B outside [1, max_rows]");
   if (mode == SDRM_RNG_EXPLICIT && (!rnd || !rnd->noise || !rnd->t || !rnd->keep))
     return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: EXPLICIT mode needs noise, t and keep");
@@ -841,6 +850,7 @@ namespace {
 // loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
 int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
+  g_nt32_cur = g_nt32_max_rows_train;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
@@ -1074,6 +1084,7 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
 
 int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mode, const uint8_t* keep, uint64_t seed,
                  uint64_t step, int64_t row0, float* out, void* stream) {
+  g_nt32_cur = g_nt32_max_rows;
   if (!e || !x || !t || !out) return fail(e, SDRM_ERR_ARG, "sdrm_forward: null pointer");
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_forward: n outside [1, 3*max_rows]");
   if (mode == SDRM_RNG_EXPLICIT && !keep) return fail(e, SDRM_ERR_ARG, "sdrm_forward: EXPLICIT mode needs keep");
@@ -1082,6 +1093,7 @@ int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mo
 }
 
 int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, const uint8_t* keep, void* stream) {
+  g_nt32_cur = g_nt32_max_rows;
   if (!e || !x || !keep) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: null pointer");
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_reverse_step: n outside [1, 3*max_rows]");
   if (i < 1 || i > e->T) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: step outside [1, T]");
@@ -1109,6 +1121,7 @@ int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const f
 int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
                       const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0,
                       int64_t* Tj_out, void* stream) {
+  g_nt32_cur = g_nt32_max_rows;
   if (!e) return SDRM_ERR_ARG;
   e->smp.active = false;
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: n outside [1, 3*max_rows]");
@@ -1178,6 +1191,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
 }
 
 int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
+  g_nt32_cur = g_nt32_max_rows;
   if (!e) return SDRM_ERR_ARG;
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_steps: no sampling call in progress");
   hipStream_t st = (hipStream_t)stream;
