@@ -19,7 +19,9 @@
  *  - All arithmetic is fp32; `t` / `Tj` are int64 as in the reference (`torch.randint`, :327).
  *  - Return value: 0 on success, negative `sdrm_status` otherwise; never throws.  The message of the
  *    last failure on a handle is returned by sdrm_last_error().
- *  - A handle is not thread-safe; distinct handles are independent.
+ *  - A handle is not thread-safe; distinct handles are independent: all tile / path selection state lives in the
+ *    handle (read from the SDRM_* environment variables once, in sdrm_create), none of it is process-global.
+ *  - Test and tuning hooks (sdrm_debug_*) are declared in sdrm_hip_debug.h, not here.
  *
  * Parameter order of every "flat" vector (P floats) = SDRM.named_parameters() of the reference
  * (train_SDRM.py:86-95):
@@ -185,6 +187,9 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
+/* Hex SHA-256 of the sources this binary was compiled from (sdrm_amd/csrc/ and include/, as sdrm_amd/_build.py hashes
+ * them).  The Python loader refuses, or rebuilds, a library whose hash differs from the sources next to it. */
+const char* sdrm_source_hash(void);
 /* Sparse batch feed (reference: dataloaders.py:46-79 builds a COO tensor per batch on the host, train_SDRM.py:323
  * densifies it before vae.encode).  The CSR matrix of the whole feed [n_rows, n_items] stays on the device (int64
  * indptr, int32 column indices, float32 data or null for all-ones); out [b, n_items] float32 receives the dense rows
@@ -214,36 +219,6 @@ int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const i
                       const int32_t* held_indices, const int64_t* train_indptr, const int32_t* train_indices,
                       const int32_t* ks_host, int nk, const double* tp, const double* idcg, double* recall, double* ndcg,
                       void* stream);
-
-/* Host-side planning of one split-K weight-gradient launch, exposed for tests (no device work): for a reduction over
- * `rows` stacked rows into an [n_out, k_in] gradient, the number of K-slices (slabs) and the rows per slice the engine
- * would use.  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows, slices <= 64, and slices
- * is a multiple of 8 whenever the rows allow eight slices of at least 128 rows (slices are pinned to the 8 XCDs). */
-int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice);
-/* Enables (default) / disables the persistent LDS-resident sampler used when the padded widths are <= 64
- * (csrc/skinny.h); with it off, narrow nets go through the general per-layer GEMM path.  Test / tuning aid. */
-int sdrm_debug_set_skinny(int on);
-/* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;
- * every other case uses the stand-alone k_reverse_update): 0 never, 1 (default) for launches of at most 4096 rows - the
- * shards of a multi-GPU run, which run on the 32x32 tile where one launch less per reverse step is worth more than the
- * epilogue's Philox work - 2 always; also env SDRM_FUSE_REV.  Results are identical up to the rounding of the update arithmetic.
- * Test / tuning aid. */
-int sdrm_debug_set_fused_reverse(int mode);
-/* Row chains of a sampling call (csrc/sdrm_hip.hip: independent row ranges run on separate HIP streams so that one
- * chain's launch gaps are filled by another's kernels): -1 = by size (default), 1..4 forced; also env SDRM_CHAINS.
- * Results do not depend on it (rows are independent and randoms are keyed by row).  Test / tuning aid. */
-int sdrm_debug_set_chains(int chains);
-/* Forces the GEMM tile shape (0 = 64x64x16 default, 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16, 4 = 32x32x32 on the 16x16x4 MFMA,
- * -1 = automatic: 64x64x16, or 32x32x32 when the launch has too few rows to fill the chip);
- * also env SDRM_TILE.  Tuning aid. */
-int sdrm_debug_set_tile(int cfg);
-/* Debug/unit-test hook: C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]),
- * A^T * B (variant 2, A is [K,M], B is [K,N]) through the same MFMA kernel the engine uses.  All
- * dims must be multiples of 32.  Stages the operands in zero-padded scratch and synchronises. */
-int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream);
-/* Same kernel timed: `reps` launches on zero-filled scratch operands, mean microseconds per launch by
- * HIP events on `stream` (tools/gemm_tune.py). */
-int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,64 @@
+/*
+ * sdrm_hip_debug.h — test and tuning hooks of libsdrm_hip.so.  NOT part of the drop-in boundary (that is
+ * sdrm_hip.h): nothing here has a counterpart in the reference, a production caller never needs it, and the
+ * signatures may change between rounds.  Used by tests/ (to force every kernel variant through the same parity
+ * checks, whatever the size thresholds currently are) and by tools/ (tile sweeps).
+ *
+ * Every setter acts on ONE handle: tile / path selection lives in the engine (sdrm_hip.h "Conventions"), so
+ * forcing a variant on one engine never changes what another engine in the same process launches.
+ */
+#ifndef SDRM_HIP_DEBUG_H
+#define SDRM_HIP_DEBUG_H
+
+#include "sdrm_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tile shapes of the MFMA GEMM template, as numbered by sdrm_debug_set_tile / the `cfg` arguments below:
+ *   0 = 64x64x16 (default), 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16 on v_mfma_f32_32x32x2_f32,
+ *   4 = 32x32x32 on v_mfma_f32_16x16x4_f32. */
+enum { SDRM_TILE_AUTO = -1, SDRM_TILE_COUNT = 5 };
+
+/* Forces the GEMM tile shape of every launch of this engine (SDRM_TILE_AUTO = automatic: 64x64x16, or 32x32x32 for NT
+ * launches of at most `nt32` rows, see sdrm_debug_set_nt32_rows); also env SDRM_TILE, read by sdrm_create.  Refused
+ * (SDRM_ERR_STATE) between a train forward and its backward and inside a sampling call: the slope partial layout of a
+ * backward is fixed by the tile its forward chose. */
+int sdrm_debug_set_tile(sdrm_engine* e, int cfg);
+/* Row thresholds of the automatic tile choice: NT launches of at most max_rows rows (sampling, plain forward; default
+ * 4096) / max_rows_train stacked rows (train step; default 8192) run on the 32x32x32 tile.  A negative value leaves
+ * that threshold alone.  Also env SDRM_NT32_MAX_ROWS / SDRM_NT32_MAX_ROWS_TRAIN. */
+int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train);
+/* Enables (default) / disables the LDS-resident kernels used when the padded widths are <= 64 (csrc/skinny.h,
+ * csrc/skinny_train.h); with them off, narrow nets go through the general per-layer GEMM path. */
+int sdrm_debug_set_skinny(sdrm_engine* e, int on);
+/* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;
+ * every other case uses the stand-alone k_reverse_update): 0 never, 1 (default) for launches of at most 4096 rows - the
+ * shards of a multi-GPU run, which run on the 32x32 tile where one launch less per reverse step is worth more than the
+ * epilogue's Philox work - 2 always; also env SDRM_FUSE_REV.  Results are identical up to the rounding of the update
+ * arithmetic. */
+int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode);
+/* Row chains of a sampling call (csrc/sdrm_hip.hip: independent row ranges run on separate HIP streams so that one
+ * chain's launch gaps are filled by another's kernels): -1 = by size (default), 1..4 forced; also env SDRM_CHAINS.
+ * Results do not depend on it (rows are independent and randoms are keyed by row). */
+int sdrm_debug_set_chains(sdrm_engine* e, int chains);
+
+/* Host-side planning of one split-K weight-gradient launch with the default settings (no device work): for a reduction
+ * over `rows` stacked rows into an [n_out, k_in] gradient, the number of K-slices (slabs) and the rows per slice the
+ * engine would use.  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows, slices <= 64, and
+ * slices is a multiple of 8 whenever the rows allow eight slices of at least 128 rows (slices are pinned to the 8 XCDs). */
+int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice);
+
+/* C[M,N] = A[M,K] * B^T (variant 0, B is [N,K]), A * B (variant 1, B is [K,N]), A^T * B (variant 2, A is [K,M], B is
+ * [K,N]) through the same MFMA kernel the engine uses, on tile shape `cfg` (0..4).  All dims must be multiples of 32.
+ * Stages the operands in zero-padded scratch and synchronises. */
+int sdrm_debug_gemm(int variant, int cfg, const float* A, const float* B, float* C, int M, int N, int K, void* stream);
+/* Same kernel timed: `reps` launches on zero-filled scratch operands, mean microseconds per launch by HIP events on
+ * `stream` (tools/gemm_tune.py). */
+int sdrm_debug_gemm_time(int variant, int cfg, int M, int N, int K, int reps, float* us_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDRM_HIP_DEBUG_H */

@@ -64,13 +64,16 @@ SIGNATURES = {
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),
     "sdrm_rank_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "sdrm_debug_set_tile": (c_int, [c_int]),
-    "sdrm_debug_set_chains": (c_int, [c_int]),
-    "sdrm_debug_set_fused_reverse": (c_int, [c_int]),
-    "sdrm_debug_set_skinny": (c_int, [c_int]),
+    "sdrm_source_hash": (C.c_char_p, []),
+    # include/sdrm_hip_debug.h (test / tuning hooks; every setter acts on one handle)
+    "sdrm_debug_set_tile": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_nt32_rows": (c_int, [c_void_p, c_int, c_int]),
+    "sdrm_debug_set_chains": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_fused_reverse": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_skinny": (c_int, [c_void_p, c_int]),
     "sdrm_debug_plan_wgrad": (c_int, [c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int)]),
-    "sdrm_debug_gemm_time": (c_int, [c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float), c_void_p]),
-    "sdrm_debug_gemm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "sdrm_debug_gemm_time": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float), c_void_p]),
+    "sdrm_debug_gemm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 RNG_EXPLICIT, RNG_PHILOX = 0, 1
@@ -83,14 +86,17 @@ def lib_path() -> str:
 
 
 def load(build_if_missing: bool = True):
-    """Loads (building first if needed) the HIP library; raises RuntimeError if that is impossible."""
+    """Loads the HIP library, rebuilding it first when it is missing or was compiled from other sources than the ones
+    next to it (`_build.is_stale()`: the SHA-256 of csrc/ + include/ compiled into the binary against the files as they
+    are now).  Raises RuntimeError if that is impossible - there is no fallback path."""
     global _LIB
     if _LIB is not None:
         return _LIB
     path = lib_path()
-    if not os.path.exists(path):
+    if _build.is_stale():
         if not build_if_missing:
-            raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            what = "is missing" if not os.path.exists(path) else "was built from different sources than csrc/ + include/"
+            raise RuntimeError(f"{path} {what}: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _build.build_library()
     try:
         lib = C.CDLL(path)
@@ -99,5 +105,8 @@ def load(build_if_missing: bool = True):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype, fn.argtypes = res, args
+    got, want = lib.sdrm_source_hash().decode(), _build.source_hash()
+    if got != want:  # pragma: no cover - is_stale() above reads the same bytes from the file
+        raise RuntimeError(f"{path} carries source hash {got[:16]}, the sources hash to {want[:16]}")
     _LIB = lib
     return lib

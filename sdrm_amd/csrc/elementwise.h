@@ -211,11 +211,12 @@ struct PrepFwdArgs {
   const float* x; const int64_t* t; int t_uniform; const uint8_t* keep;
   float* U; int n, L, LP, K0, T, MP;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0;
+  int bpr;   // work-groups per row: the row is folded into grid.x (grid.y stops at 65535, max_rows does not)
 };
 
 __global__ __launch_bounds__(256) void k_prep_forward(const PrepFwdArgs a) {
-  const int r = blockIdx.y;
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int r = blockIdx.x / a.bpr;
+  const int q = (blockIdx.x - r * a.bpr) * 256 + threadIdx.x;
   const int c = 2 * q;
   if (c >= a.K0 || r >= a.MP) return;
   float2 o = make_float2(0.f, 0.f);
@@ -662,11 +663,12 @@ struct SampleInitArgs {
   const float* xT; const uint8_t* keep; const int64_t* Tj; const int* rowid;
   float* X; float* U; int n, L, LP, K0, MP, T;
   int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
+  int bpr;   // work-groups per row (row folded into grid.x)
 };
 
 __global__ __launch_bounds__(256) void k_sample_init(const SampleInitArgs a) {
-  const int s = blockIdx.y;
-  const int q = blockIdx.x * 256 + threadIdx.x;   // column quad: one Philox call, 16-byte stores
+  const int s = blockIdx.x / a.bpr;
+  const int q = (blockIdx.x - s * a.bpr) * 256 + threadIdx.x;   // column quad: one Philox call, 16-byte stores
   const int c = 4 * q;
   if (c >= a.LP || s >= a.MP) return;
   float x[4] = {0.f, 0.f, 0.f, 0.f}, u[4] = {0.f, 0.f, 0.f, 0.f};
@@ -712,11 +714,13 @@ struct ReverseArgs {
   float* X; const float* Y; float* U; const float* Z; const uint8_t* keep_next; const int64_t* Tj; const int* rowid;
   int s0, n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
   int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
+  int bpr;   // work-groups per row (row folded into grid.x)
 };
 
 __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
-  const int s = a.s0 + blockIdx.y;               // slot; this launch covers the active slots [s0, n) of one row chain
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int rr = blockIdx.x / a.bpr;
+  const int s = a.s0 + rr;                       // slot; this launch covers the active slots [s0, n) of one row chain
+  const int q = (blockIdx.x - rr * a.bpr) * 256 + threadIdx.x;
   const int c = 4 * q;
   if (c >= a.L || s >= a.n) return;
   const int r = a.rowid ? a.rowid[s] : s;       // original row: indexes explicit randoms and keys Philox

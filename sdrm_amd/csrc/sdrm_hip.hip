@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/sdrm_hip.h"
+#include "../../include/sdrm_hip_debug.h"
 #include "elementwise.h"
 #include "feed.h"
 #include "gemm.h"
@@ -23,18 +24,35 @@ using namespace sdrm;
 
 namespace {
 
-constexpr int BM = 64, BN = 64;     // row padding granule = rows of the default tile (the 128-row alternates read into
+constexpr int BM = 64;              // row padding granule = rows of the default tile (the 128-row alternates read into
                                     // the slack every buffer carries, and write rows nobody reads)
 constexpr int S_MAX = 64;          // max split-K slabs per weight-gradient GEMM
-int g_wgrad_blocks = 1024;           // work-groups a wgrad launch aims for (SDRM_WGRAD_BLOCKS env: tuning aid)
 constexpr int LOSS_BLOCKS = 256;
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+// Tile / path selection of ONE engine: read from the environment once, in sdrm_create, changed afterwards only by the
+// sdrm_debug_* setters of that handle (include/sdrm_hip_debug.h).  Nothing here is process-global: two engines on two
+// threads never see each other's settings.
+struct Tuning {
+  int force_cfg = -1;            // SDRM_TILE: -1 = automatic, 0..4 forced tile shape
+  int chains = -1;               // SDRM_CHAINS: sampler row chains, -1 = by size, 1..4 forced
+  int fuse_rev = 1;              // SDRM_FUSE_REV: reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX
+                                 // sampling): 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always
+  int skinny = 1;                // LDS-resident kernels for nets with padded widths <= 64 (persistent sampler, fused train
+                                 // forward and dgrad chain)
+  int nt32_max_rows = 4096;      // SDRM_NT32_MAX_ROWS: sampling / plain-forward NT launches of at most this many rows use the 32x32 tile
+  int nt32_max_rows_train = 8192;  // SDRM_NT32_MAX_ROWS_TRAIN: the same for the train step's launches (stacked rows = 3 x batch):
+                                 // 6144 stacked rows (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile,
+                                 // 12288 a tie; the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
+  int wgrad_blocks = 1024;       // SDRM_WGRAD_BLOCKS: work-groups a wgrad launch aims for
+};
+
 struct sdrm_engine {
   int L, W, T, H, max_rows, device;
+  Tuning tune;
   int LP, WP, TP, K0, MPmax;
   int64_t P;
   int64_t off_we, off_be, off_w0, off_b0, off_a0, off_wh, off_bh, off_ah, off_wo, off_bo;
@@ -71,6 +89,9 @@ struct sdrm_engine {
   bool bwd_begun = false;
   bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
+  int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
+  uint64_t params_version = 0;       // bumped whenever the parameters change (set_params, Adam)
+  uint64_t smp_b0_version = 0;       // parameters the sampler's bias table B0tab was built from
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
@@ -152,46 +173,25 @@ typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16
 constexpr int N_TILE_CFGS = 5;
 const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
 const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
-int g_force_cfg = -1;  // SDRM_TILE env / sdrm_debug_set_tile override (tuning aid)
-int g_chains = -1;     // sampler row chains: -1 = by size, 1..4 forced (SDRM_CHAINS env / sdrm_debug_set_chains)
-int g_fuse_rev = 1;    // reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX sampling):
-                       // 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always (SDRM_FUSE_REV env)
 constexpr int FUSE_REV_MAX_ROWS = 4096;   // = the launches that run on the 32x32 tile (4 accumulator rows per lane: two Philox calls);
                                           // measured (tools/shard_probe.py): 679 / 1358 / 2715 rows 21.1 / 24.9 / 36.6 -> 18.8 / 22.6 / 33.7 us per step;
                                           // on the 64x64 tile (16 rows per lane) 5429 rows 54.3 -> 56.9
-int g_skinny = 1;      // LDS-resident kernels for nets with padded widths <= 64: persistent sampler, fused train forward and
-                       // dgrad chain (sdrm_debug_set_skinny)
 
-int pick_cfg(int /*M*/, int /*N*/, int /*K*/ = 0) {
-  return (g_force_cfg >= 0 && g_force_cfg < N_TILE_CFGS) ? g_force_cfg : 0;
-}
+// Tile of a split-K (weight-gradient) launch: the forced one, else the default.
+int pick_cfg(const Tuning& t) { return (t.force_cfg >= 0 && t.force_cfg < N_TILE_CFGS) ? t.force_cfg : 0; }
 
-int g_nt32_max_rows = 4096;   // sampling / plain-forward NT launches of at most this many rows use the 32x32 tile
-                              // (SDRM_NT32_MAX_ROWS env: tuning aid)
-int g_nt32_max_rows_train = 8192;   // the same for the train step's launches (stacked rows = 3 x batch): 6144 stacked rows
-                                    // (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile, 12288 a tie;
-                                    // the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
-                                    // (SDRM_NT32_MAX_ROWS_TRAIN env)
-int g_nt32_cur = 4096;        // the threshold in force: set by the entry point that is about to launch
-
-// Tile for an unsplit (NT) launch.  With the k-minor LDS image and ds_read_b128 fragments the 32x32x32 tile on the
-// 16-wide MFMA has no ragged tile (352 = 11 x 32), four times the work-groups and a quarter of the dependent MFMA
-// chain per wave.  Stand-alone (tools/gemm_tune.py, operands hot in L2) it matches or beats 64x64x16 at every size;
-// inside the step, where every operand was just written by the previous launch, it wins up to a few thousand rows
-// and loses above (tools/shard_probe.py, sample step at 679 / 1358 / 2715 / 5429 rows: 19.3 / 25.6 / 36.9 / 60.1 us
-// against 23.5 / 31.6 / 49.9 / 54.2; train step at 3072 / 6144 / 12288 / 24576 stacked rows: 156 / 235 / 375 / 683
-// against 170 / 235 / 363 / 629) - the 64x64 tile moves half
-// the operand bytes per flop.  (64x32 and 32x64 tiles on the 16-wide MFMA were tried for the large launches: 644 / 661 us per
-// train step against 618.)
-int choose_cfg(int M, int N, int K) {
-  int cfg = pick_cfg(M, N, K);
-  if (cfg == 0 && g_force_cfg < 0 && M <= g_nt32_cur) cfg = 4;
-  return cfg;
-}
-
-int gemm_blocks(int M, int N, int K) {
-  const int c = choose_cfg(M, N, K);
-  return ((M + kCfgBM[c] - 1) / kCfgBM[c]) * ((N + kCfgBN[c] - 1) / kCfgBN[c]);
+// Tile for an unsplit (NT) launch of M rows; `nt32_rows` is the caller's threshold (Tuning::nt32_max_rows for sampling
+// and plain forwards, ::nt32_max_rows_train for the train step).  With the k-minor LDS image and ds_read_b128
+// fragments the 32x32x32 tile on the 16-wide MFMA has no ragged tile (352 = 11 x 32), four times the work-groups and a
+// quarter of the dependent MFMA chain per wave.  Stand-alone (tools/gemm_tune.py, operands hot in L2) it matches or
+// beats 64x64x16 at every size; inside the step, where every operand was just written by the previous launch, it wins
+// up to a few thousand rows and loses above (tools/shard_probe.py, sample step at 679 / 1358 / 2715 / 5429 rows:
+// 19.3 / 25.6 / 36.9 / 60.1 us against 23.5 / 31.6 / 49.9 / 54.2; train step at 3072 / 6144 / 12288 / 24576 stacked
+// rows: 156 / 235 / 375 / 683 against 170 / 235 / 363 / 629) - the 64x64 tile moves half the operand bytes per flop.
+// (64x32 and 32x64 tiles on the 16-wide MFMA were tried for the large launches: 644 / 661 us per train step against 618.)
+int choose_cfg(const Tuning& t, int M, int nt32_rows) {
+  if (t.force_cfg >= 0 && t.force_cfg < N_TILE_CFGS) return t.force_cfg;
+  return M <= nt32_rows ? 4 : 0;
 }
 
 int max_gemm_blocks(int M, int N) {
@@ -227,9 +227,7 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
 }
 
 template <int LA, int LB, int XA, int XB, int EPI>
-hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0},
-                       int cfg = -1) {
-  if (cfg < 0) cfg = (splits > 1) ? pick_cfg(M, N, a.kchunk) : choose_cfg(M, N, a.kchunk);
+hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr, int cfg) {
   switch (cfg) {
     case 1: return launch_gemm_cfg<Cfg1, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     case 2: return launch_gemm_cfg<Cfg2, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
@@ -242,11 +240,11 @@ hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Pr
 // forward Linear: C[M,N] = act(xf(A)[M,K] * Wc[N,K]^T + bias)
 template <int XA, int EPI>
 hipError_t gemm_forward(GemmArgs a, const float* A, int lda, const float* Wc, int ldw, int M, int N, int K,
-                        hipStream_t st, Prof pr = Prof{nullptr, 0, 0.0}) {
+                        hipStream_t st, Prof pr, int cfg) {
   a.A = A; a.lda = lda; a.limA = M;
   a.B = Wc; a.ldb = ldw; a.limB = N;
   a.K = K; a.kchunk = K;
-  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st, pr);
+  return launch_gemm<LD_KCONTIG, LD_KCONTIG, XA, XF_NONE, EPI>(a, M, N, 1, st, pr, cfg);
 }
 
 // dgrad: C[M,Kin] = (dC[M,Nout] * W[Nout,Kin]) * prelu'(aux), against the transposed copy WT[Kin][Nout] (NT form)
@@ -265,7 +263,7 @@ hipError_t gemm_dgrad(sdrm_engine* e, const float* dC, int lddc, const float* WT
 // wgrad: slab[s][Nout,Kin] = dC[rows s][.,Nout]^T * xf(Act)[rows s][., Kin] ; dbias[s][Nout] = column sums of dC
 template <int XB>
 hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int ldact, int Kin, const float* slopeB,
-                      int Mrows, int S, int kchunk, float* slab, float* dbias, hipStream_t st, Prof pr) {
+                      int Mrows, int S, int kchunk, float* slab, float* dbias, hipStream_t st, Prof pr, int cfg) {
   GemmArgs a{};
   a.A = dC; a.lda = lddc; a.limA = Nout;
   a.B = Act; a.ldb = ldact; a.limB = Kin;
@@ -274,7 +272,7 @@ hipError_t gemm_wgrad(const float* dC, int lddc, int Nout, const float* Act, int
   a.slopeB = slopeB;
   a.slab_stride = (size_t)Nout * Kin;
   a.dbias = dbias; a.dbias_stride = Nout;
-  return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st, pr);
+  return launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XB, EPI_SLAB>(a, Nout, Kin, S, st, pr, cfg);
 }
 
 // One weight gradient of a batched launch (gemm_batch_kernel): the arguments gemm_wgrad would pass, with the grid
@@ -319,11 +317,11 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
   return rc;
 }
 
-void pick_splits(int Mrows, int Nout, int Kin, int& S, int& kchunk) {
-  const int c = pick_cfg(Nout, Kin, 4096);
+void pick_splits(const Tuning& tn, int Mrows, int Nout, int Kin, int& S, int& kchunk) {
+  const int c = pick_cfg(tn);
   const int tiles = ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
   const int BK = 32;
-  int want = g_wgrad_blocks / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
+  int want = tn.wgrad_blocks / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
   if (max_by_rows < 1) max_by_rows = 1;
   S = want < 1 ? 1 : want;
@@ -418,7 +416,7 @@ int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
   return SDRM_OK;
 }
 
-bool skinny_net(const sdrm_engine* e) { return g_skinny && e->LP <= 64 && e->WP <= 64; }
+bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && e->WP <= 64; }
 
 SkinnyTrainArgs skinny_train_args(sdrm_engine* e, int B, int MP) {
   SkinnyTrainArgs a{};
@@ -464,14 +462,14 @@ int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hi
 
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
 // (its bias / K differ between training and sampling).
-int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int r0 = 0, int cls = PC_FWD_HIDDEN) {
+int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, int r0 = 0, int cls = PC_FWD_HIDDEN) {
   const double fl = 2.0 * rows * (double)e->W * e->W;
   const size_t ro = (size_t)r0 * e->WP;
   for (int k = 1; k <= e->H; ++k) {
     GemmArgs a{};
     a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
     HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1) + ro, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
-                                                 Prof{e, cls, fl})));
+                                                 Prof{e, cls, fl}, cfg)));
   }
   return SDRM_OK;
 }
@@ -491,8 +489,8 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 
 // Row chains for a sampling call of n rows.  Measured (tools/chain_sweep.py): worthwhile once every chain
 // still has a few hundred rows.
-int chains_for(int n) {
-  if (g_chains >= 1) return g_chains > 4 ? 4 : g_chains;
+int chains_for(const Tuning& t, int n) {
+  if (t.chains >= 1) return t.chains > 4 ? 4 : t.chains;
   (void)n;
   return 1;
 }
@@ -558,36 +556,58 @@ void reverse_coeffs(const sdrm_engine* e, int i, float& c1, float& sa, float& sb
 // =================================================================================================
 extern "C" {
 
-int sdrm_debug_set_skinny(int on) {
-  g_skinny = on ? 1 : 0;
+int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.skinny = on ? 1 : 0;
   return SDRM_OK;
 }
 
 int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice) {
   if (!slices || !rows_per_slice || rows < 1 || n_out < 1 || k_in < 1) return SDRM_ERR_ARG;
-  pick_splits(rows, n_out, k_in, *slices, *rows_per_slice);
+  pick_splits(Tuning{}, rows, n_out, k_in, *slices, *rows_per_slice);
   return SDRM_OK;
 }
 
-int sdrm_debug_set_fused_reverse(int mode) {
-  g_fuse_rev = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.fuse_rev = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   return SDRM_OK;
 }
 
-int sdrm_debug_set_chains(int chains) {
-  g_chains = chains;
+int sdrm_debug_set_chains(sdrm_engine* e, int chains) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.chains = chains;
   return SDRM_OK;
 }
 
-int sdrm_debug_set_tile(int cfg) {
-  g_force_cfg = cfg;
+int sdrm_debug_set_tile(sdrm_engine* e, int cfg) {
+  if (!e) return SDRM_ERR_ARG;
+  if (e->fwd_done || e->bwd_begun || e->smp.active)
+    return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_tile: a train step or a sampling call is in progress");
+  e->tune.force_cfg = cfg;
   return SDRM_OK;
 }
+
+int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train) {
+  if (!e) return SDRM_ERR_ARG;
+  if (max_rows >= 0) e->tune.nt32_max_rows = max_rows;
+  if (max_rows_train >= 0) e->tune.nt32_max_rows_train = max_rows_train;
+  return SDRM_OK;
+}
+
+#ifndef SDRM_SOURCE_HASH
+#define SDRM_SOURCE_HASH "unhashed"
+#endif
+// "SDRM_SOURCE_HASH=<hex>" is also what sdrm_amd/_build.py looks for in the file to decide whether the binary belongs to
+// the sources next to it.
+static const char kSourceHashMarker[] = "SDRM_SOURCE_HASH=" SDRM_SOURCE_HASH;
+const char* sdrm_source_hash(void) { return kSourceHashMarker + sizeof("SDRM_SOURCE_HASH=") - 1; }
 
 const char* sdrm_build_info(void) {
-  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (32x32x32 on v_mfma_f32_16x16x4_f32 for launches of <=256 "
-         "such tiles), 4 waves, two LDS stages + register-double-buffered fragments, pipeline pieces in the MFMA shadows, "
-         "k-minor LDS + ds_read_b128 for NT; split-K slabs for wgrad; persistent LDS-resident sampler for widths <= 64";
+  return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (32x32x32 on v_mfma_f32_16x16x4_f32 for NT launches of at "
+         "most 4096 rows, 8192 stacked rows in the train step), 4 waves, two LDS stages + register-double-buffered fragments, "
+         "pipeline pieces in the MFMA shadows, k-minor LDS + ds_read_b128 for NT; split-K slabs for wgrad; persistent "
+         "LDS-resident kernels for widths <= 64; sources " SDRM_SOURCE_HASH;
 }
 
 const char* sdrm_last_error(const sdrm_engine* e) { return e ? e->err.c_str() : "null engine"; }
@@ -599,14 +619,14 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (L < 1 || L > 4096 || W < 1 || W > 4096 || T < 2 || T > 1024 || H < 0 || H > 16 || max_rows < 1 ||
       max_rows > (1 << 22))
     return SDRM_ERR_SHAPE;
-  if (const char* env = std::getenv("SDRM_TILE")) g_force_cfg = std::atoi(env);
-  if (const char* env = std::getenv("SDRM_CHAINS")) g_chains = std::atoi(env);
-  if (const char* env = std::getenv("SDRM_FUSE_REV")) g_fuse_rev = std::atoi(env);
-  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) g_nt32_max_rows = std::atoi(env);
-  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) g_nt32_max_rows_train = std::atoi(env);
-  g_nt32_cur = g_nt32_max_rows;
-  if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) g_wgrad_blocks = std::atoi(env);
   sdrm_engine* e = new sdrm_engine();
+  // the only place the environment is read: the settings then belong to this handle
+  if (const char* env = std::getenv("SDRM_TILE")) e->tune.force_cfg = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_CHAINS")) e->tune.chains = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_FUSE_REV")) e->tune.fuse_rev = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) e->tune.wgrad_blocks = std::max(1, std::atoi(env));
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
   e->MPmax = round_up(3 * max_rows, 128);
@@ -713,6 +733,7 @@ int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int jr = join_chains(e, st)) return jr;
   HIP_TRY(e, hipMemcpyAsync(e->p, flat, e->P * 4, hipMemcpyDeviceToDevice, st));
+  e->params_version++;
   return launch_adam(e, nullptr, 0.f, 0, st);  // re-pack only
 }
 
@@ -759,7 +780,6 @@ int sdrm_adam_reset(sdrm_engine* e, void* stream) {
 int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd,
                        uint64_t seed, uint64_t step, float nd, double* sums, void* stream) {
   if (!e || !x0) return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: null pointer");
-  g_nt32_cur = g_nt32_max_rows_train;
   if (B < 1 || B > e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_train_forward: B outside [1, max_rows]");
   if (mode == SDRM_RNG_EXPLICIT && (!rnd || !rnd->noise || !rnd->t || !rnd->keep))
     return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: EXPLICIT mode needs noise, t and keep");
@@ -767,12 +787,14 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   hipStream_t st = (hipStream_t)stream;
   if (int jr = join_chains(e, st)) return jr;
   const int MP = round_up(3 * B, BM), n = e->T + 1;
+  const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
 
   if (skinny_net(e)) {
     // narrow net: tables (B0tab = b0 + C0[t], E for the embedding backward), then staging and all layers in one launch
     int rc = emb_tables(e, true, st);
     if (rc) return rc;
+    e->smp_b0_version = e->params_version;
     SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
     ka.x0 = x0;
     if (mode == SDRM_RNG_EXPLICIT) { ka.noise = rnd->noise; ka.t = rnd->t; ka.keep = rnd->keep; }
@@ -813,16 +835,16 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
-                                                Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)})));
+                                                Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)}, cfg)));
   }
-  int rc = hidden_forward(e, MP, 3 * B, st);
+  int rc = hidden_forward(e, MP, 3 * B, st, cfg);
   if (rc) return rc;
   {
     GemmArgs a{};
     a.C = e->Y; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
     a.rows_valid = MP; a.cols_valid = e->LP;
     HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
-                                                      Prof{e, PC_FWD_OUT, 2.0 * 3 * B * (double)e->L * e->W})));
+                                                      Prof{e, PC_FWD_OUT, 2.0 * 3 * B * (double)e->L * e->W}, cfg)));
   }
   LossArgs la{};
   la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
@@ -850,7 +872,6 @@ namespace {
 // loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
 int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
-  g_nt32_cur = g_nt32_max_rows_train;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
@@ -861,11 +882,13 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     HIP_TRY(e, hipGetLastError());
   }
   int S0, SH, SO, kc0, kcH, kcO;
-  pick_splits(MP, e->WP, e->K0, S0, kc0);
-  pick_splits(MP, e->WP, e->WP, SH, kcH);
-  pick_splits(MP, e->LP, e->WP, SO, kcO);
+  pick_splits(e->tune, MP, e->WP, e->K0, S0, kc0);
+  pick_splits(e->tune, MP, e->WP, e->WP, SH, kcH);
+  pick_splits(e->tune, MP, e->LP, e->WP, SO, kcO);
   // every dgrad writes [MP,WP]: one tile shape for all of them, so the slope partial counts agree
-  const int cfg_d = choose_cfg(MP, e->WP, e->WP);
+  const int cfg_d = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);
+  const int cfg_w = pick_cfg(e->tune);   // tile of every split-K launch of this backward (backward_wgrads reuses it)
+  e->bwd_cfg_w = cfg_w;
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
@@ -876,7 +899,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     if (rc) return rc;
     if (with_wgrad0)
       HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
-                                      Prof{e, PC_WGRAD_L0, fl0})));
+                                      Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
     e->bwd_kc0 = kc0;
     e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = MP / 16;
     e->bwd_kcH = kcH; e->bwd_kcO = kcO;
@@ -891,7 +914,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   // layer 0 (no latent dgrad: XT.grad is never read, Q7)
   if (with_wgrad0)
     HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
-                                    Prof{e, PC_WGRAD_L0, fl0})));
+                                    Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
   e->bwd_kc0 = kc0;
   e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = dgrad_blocks;
   e->bwd_kcH = kcH; e->bwd_kcO = kcO;
@@ -906,16 +929,17 @@ int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
-  if (g_force_cfg > 0) {
+  if (e->bwd_cfg_w > 0) {   // a forced tile other than the default: the batched kernel is built for the default only
+    const int cfg_w = e->bwd_cfg_w;
     if (with_wgrad0)
       HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, e->bwd_S0, e->bwd_kc0, e->slab0,
-                                      e->db0s, st, Prof{e, PC_WGRAD_L0, fl0})));
+                                      e->db0s, st, Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
     HIP_TRY(e, (gemm_wgrad<XF_PRELU>(e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), MP, SO, e->bwd_kcO,
-                                     e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO})));
+                                     e->slabO, e->dbOs, st, Prof{e, PC_WGRAD, flO}, cfg_w)));
     for (int k = H; k >= 1; --k)
       HIP_TRY(e, (gemm_wgrad<XF_PRELU>(dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), MP, SH,
                                        e->bwd_kcH, e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP,
-                                       e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH})));
+                                       e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH}, cfg_w)));
     return SDRM_OK;
   }
   std::vector<WgradSpec> w;
@@ -1026,6 +1050,7 @@ int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
   if (!e) return SDRM_ERR_ARG;
   if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
   e->adam_t += 1;
+  e->params_version++;
   return launch_adam(e, grad, lr, 1, (hipStream_t)stream);
 }
 
@@ -1056,12 +1081,14 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
                         int cols_valid, hipStream_t st) {
   if (int jr = join_chains(e, st)) return jr;
   const int MP = round_up(n, BM);
+  const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows);
   PrepFwdArgs pa{};
   pa.x = x; pa.t = t; pa.t_uniform = t_uniform; pa.keep = keep; pa.U = e->U;
   pa.n = n; pa.L = e->L; pa.LP = e->LP; pa.K0 = e->K0; pa.T = e->T; pa.MP = MP;
   pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
   pa.row0 = row0;
-  dim3 grid((e->K0 / 2 + 255) / 256, MP);
+  pa.bpr = (e->K0 / 2 + 255) / 256;
+  dim3 grid((unsigned)((size_t)pa.bpr * MP));
   hipLaunchKernelGGL(k_prep_forward, grid, dim3(256), 0, st, pa);
   HIP_TRY(e, hipGetLastError());
   int rc = emb_tables(e, false, st);
@@ -1070,21 +1097,20 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
-                                                Prof{e, PC_FWD_L0, 2.0 * n * (double)e->W * (e->L + e->T)})));
+                                                Prof{e, PC_FWD_L0, 2.0 * n * (double)e->W * (e->L + e->T)}, cfg)));
   }
-  rc = hidden_forward(e, MP, n, st);
+  rc = hidden_forward(e, MP, n, st, cfg);
   if (rc) return rc;
   GemmArgs a{};
   a.C = out; a.ldc = ldout; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
   a.rows_valid = n; a.cols_valid = cols_valid;
   HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH_G>(a, pre_buf(e, e->H), e->WP, e->Woc, e->WP, MP, e->LP, e->WP, st,
-                                                    Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W})));
+                                                    Prof{e, PC_FWD_OUT, 2.0 * n * (double)e->L * e->W}, cfg)));
   return SDRM_OK;
 }
 
 int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mode, const uint8_t* keep, uint64_t seed,
                  uint64_t step, int64_t row0, float* out, void* stream) {
-  g_nt32_cur = g_nt32_max_rows;
   if (!e || !x || !t || !out) return fail(e, SDRM_ERR_ARG, "sdrm_forward: null pointer");
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_forward: n outside [1, 3*max_rows]");
   if (mode == SDRM_RNG_EXPLICIT && !keep) return fail(e, SDRM_ERR_ARG, "sdrm_forward: EXPLICIT mode needs keep");
@@ -1093,7 +1119,6 @@ int sdrm_forward(sdrm_engine* e, const float* x, const int64_t* t, int n, int mo
 }
 
 int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, const uint8_t* keep, void* stream) {
-  g_nt32_cur = g_nt32_max_rows;
   if (!e || !x || !keep) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: null pointer");
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_reverse_step: n outside [1, 3*max_rows]");
   if (i < 1 || i > e->T) return fail(e, SDRM_ERR_ARG, "sdrm_reverse_step: step outside [1, T]");
@@ -1121,7 +1146,6 @@ int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const f
 int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
                       const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0,
                       int64_t* Tj_out, void* stream) {
-  g_nt32_cur = g_nt32_max_rows;
   if (!e) return SDRM_ERR_ARG;
   e->smp.active = false;
   if (n < 1 || n > 3 * e->max_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_sample: n outside [1, 3*max_rows]");
@@ -1133,11 +1157,12 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   if (int jr = join_chains(e, st)) return jr;
   const int T = e->T, L = e->L, MP = round_up(n, BM);
   e->fwd_done = false;
-  e->n_chains = chains_for(n);
+  e->n_chains = chains_for(e->tune, n);
   e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
   int rc = emb_tables(e, true, st);
   if (rc) return rc;
+  e->smp_b0_version = e->params_version;
   int i_start = T;
   e->smp_nact.assign(T + 2, n);                       // n_act[i] = rows with Tj >= i (all rows when full resolution)
   if (multires) {
@@ -1173,7 +1198,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
       HIP_TRY(e, hipMemcpyAsync(Tj_out, e->smp_tj_orig.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
     }
   }
-  const bool skinny = g_skinny && e->LP <= 64 && e->WP <= 64;
+  const bool skinny = skinny_net(e);
   if (skinny) {
     e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, true, false, i_start};
     return SDRM_OK;
@@ -1183,7 +1208,8 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   ia.X = e->X; ia.U = e->Us; ia.n = n; ia.L = L; ia.LP = e->LP; ia.K0 = e->LP; ia.MP = MP; ia.T = T;
   ia.mode = mode; ia.seed_lo = (uint32_t)seed; ia.seed_hi = (uint32_t)(seed >> 32);
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
-  dim3 grid((e->LP / 4 + 255) / 256, MP);
+  ia.bpr = (e->LP / 4 + 255) / 256;
+  dim3 grid((unsigned)((size_t)ia.bpr * MP));
   hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
   HIP_TRY(e, hipGetLastError());
   e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, false, false, i_start};
@@ -1191,7 +1217,6 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
 }
 
 int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
-  g_nt32_cur = g_nt32_max_rows;
   if (!e) return SDRM_ERR_ARG;
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_steps: no sampling call in progress");
   hipStream_t st = (hipStream_t)stream;
@@ -1235,6 +1260,17 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     s.i_next = s.i_next > count ? s.i_next - count : 0;
     return SDRM_OK;
   }
+  // The per-layer path runs in the buffers the train step shares (pre-activations, eps-net outputs): a forward that was
+  // waiting for its backward is gone.
+  e->fwd_done = false;
+  e->bwd_begun = false;
+  // Train steps may run between sdrm_sample_steps calls (bench.py interleaves them): the weights' compute copies follow
+  // Adam by themselves, the folded bias table b0 + C0[i] is rebuilt here when the parameters moved since it was made.
+  if (e->smp_b0_version != e->params_version) {
+    int rc = emb_tables(e, true, st);
+    if (rc) return rc;
+    e->smp_b0_version = e->params_version;
+  }
   if (e->n_chains > 1 && !e->chains_pending) {       // fork: the other chains start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
     for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
@@ -1248,17 +1284,18 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       if (s1 <= s0) break;
       hipStream_t sc = c == 0 ? st : e->aux[c - 1];
       const int rows = s1 - s0, MP = round_up(rows, BM);
+      const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows);
       {
         GemmArgs a{};
         a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
         HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->Us + (size_t)s0 * e->LP, e->LP, e->W0c, e->K0, MP, e->WP, e->LP, sc,
-                                                    Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)})));
+                                                    Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)}, cfg)));
       }
-      int rc = hidden_forward(e, MP, rows, sc, s0, PC_SMP_HIDDEN);
+      int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN);
       if (rc) return rc;
       float c1, sqrt_alpha, sqrt_beta;
       reverse_coeffs(e, i, c1, sqrt_alpha, sqrt_beta);
-      const bool fused = !s.multires && s.mode == SDRM_RNG_PHILOX && (g_fuse_rev == 2 || (g_fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
+      const bool fused = !s.multires && s.mode == SDRM_RNG_PHILOX && (e->tune.fuse_rev == 2 || (e->tune.fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
       {
         GemmArgs a{};
         a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
@@ -1272,11 +1309,11 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
           a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
           a.rev_row0 = s.row0;
           HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
-                                                           e->LP, e->WP, sc, pr)));
+                                                           e->LP, e->WP, sc, pr, cfg)));
           continue;
         }
         HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
-                                                          e->LP, e->WP, sc, pr)));
+                                                          e->LP, e->WP, sc, pr, cfg)));
       }
       ReverseArgs ra{};
       ra.X = e->X; ra.Y = e->Y; ra.U = e->Us;
@@ -1288,7 +1325,8 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ra.c1 = c1; ra.sqrt_alpha = sqrt_alpha; ra.sqrt_beta = sqrt_beta;
       ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
       ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
-      hipLaunchKernelGGL(k_reverse_update, dim3(((L + 3) / 4 + 255) / 256, rows), dim3(256), 0, sc, ra);
+      ra.bpr = ((L + 3) / 4 + 255) / 256;
+      hipLaunchKernelGGL(k_reverse_update, dim3((unsigned)((size_t)ra.bpr * rows)), dim3(256), 0, sc, ra);
       HIP_TRY(e, hipGetLastError());
     }
   }
@@ -1466,8 +1504,8 @@ int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* l
 }
 
 // ---------------------------------------------------------------------------------------------
-int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
-  if (!A || !B || !C) return SDRM_ERR_ARG;
+int sdrm_debug_gemm(int variant, int cfg, const float* A, const float* B, float* C, int M, int N, int K, void* stream) {
+  if (!A || !B || !C || cfg < 0 || cfg >= N_TILE_CFGS) return SDRM_ERR_ARG;
   if (M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2) return SDRM_ERR_SHAPE;
   hipStream_t st = (hipStream_t)stream;
   // The kernel reads whole tiles without bounds checks, so stage the caller's matrices in zero-padded
@@ -1488,9 +1526,10 @@ int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M
   a.C = dC; a.ldc = Np; a.K = K; a.kchunk = K;
   a.A = dA; a.lda = ac; a.limA = M; a.B = dB; a.ldb = bc; a.limB = N;
   if (rc == hipSuccess) {
-    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    const Prof np{nullptr, 0, 0.0};
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
   }
   if (rc == hipSuccess)
     rc = hipMemcpy2DAsync(C, (size_t)N * 4, dC, (size_t)Np * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st);
@@ -1502,7 +1541,8 @@ int sdrm_debug_gemm(int variant, const float* A, const float* B, float* C, int M
 /* Timing variant of the hook for tools/gemm_tune.py: same kernel, `reps` launches on pre-padded scratch,
  * returns the mean microseconds per launch measured with HIP events on `stream`. */
 #ifdef SDRM_STAMPS
-extern "C" int sdrm_debug_gemm_stamps(int variant, int M, int N, int K, unsigned long long* host_out, int max_blocks) {
+extern "C" int sdrm_debug_gemm_stamps(int variant, int cfg, int M, int N, int K, unsigned long long* host_out, int max_blocks) {
+  if (cfg < 0 || cfg >= N_TILE_CFGS) return SDRM_ERR_ARG;
   const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
   const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
   const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;
@@ -1516,9 +1556,10 @@ extern "C" int sdrm_debug_gemm_stamps(int variant, int M, int N, int K, unsigned
   a.A = dA; a.lda = ac; a.limA = M; a.B = dB; a.ldb = bc; a.limB = N;
   hipError_t rc = hipSuccess;
   for (int i = 0; i < 3 && rc == hipSuccess; ++i) {
-    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
-    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
-    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr);
+    const Prof np{nullptr, 0, 0.0};
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr, np, cfg);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr, np, cfg);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, nullptr, np, cfg);
   }
   if (rc == hipSuccess) rc = hipDeviceSynchronize();
   const int nb = a.nblocks < max_blocks ? a.nblocks : max_blocks;
@@ -1528,8 +1569,8 @@ extern "C" int sdrm_debug_gemm_stamps(int variant, int M, int N, int K, unsigned
 }
 #endif
 
-int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_out, void* stream) {
-  if (!us_out || reps < 1 || M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2) return SDRM_ERR_ARG;
+int sdrm_debug_gemm_time(int variant, int cfg, int M, int N, int K, int reps, float* us_out, void* stream) {
+  if (!us_out || reps < 1 || M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2 || cfg < 0 || cfg >= N_TILE_CFGS) return SDRM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
   const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
@@ -1546,9 +1587,10 @@ int sdrm_debug_gemm_time(int variant, int M, int N, int K, int reps, float* us_o
   hipError_t rc = hipSuccess;
   for (int i = 0; i < reps + 3 && rc == hipSuccess; ++i) {
     if (i == 3) (void)hipEventRecord(e0, st);
-    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
-    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st);
+    const Prof np{nullptr, 0, 0.0};
+    if (variant == 0) rc = launch_gemm<LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
+    else if (variant == 1) rc = launch_gemm<LD_KCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
+    else rc = launch_gemm<LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_PLAIN>(a, M, N, 1, st, np, cfg);
   }
   (void)hipEventRecord(e1, st);
   if (rc == hipSuccess) rc = hipStreamSynchronize(st);

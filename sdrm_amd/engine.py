@@ -72,6 +72,23 @@ class Engine:
             t = torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
         return t.contiguous()
 
+    def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None):
+        """Test / tuning hooks of THIS engine (include/sdrm_hip_debug.h): force a GEMM tile shape (-1 = automatic),
+        switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds."""
+        if tile is not None:
+            self._check(self.lib.sdrm_debug_set_tile(self._h, int(tile)), "sdrm_debug_set_tile")
+        if skinny is not None:
+            self._check(self.lib.sdrm_debug_set_skinny(self._h, int(bool(skinny))), "sdrm_debug_set_skinny")
+        if fused_reverse is not None:
+            self._check(self.lib.sdrm_debug_set_fused_reverse(self._h, int(fused_reverse)), "sdrm_debug_set_fused_reverse")
+        if chains is not None:
+            self._check(self.lib.sdrm_debug_set_chains(self._h, int(chains)), "sdrm_debug_set_chains")
+        if nt32_rows is not None or nt32_rows_train is not None:
+            self._check(self.lib.sdrm_debug_set_nt32_rows(self._h, -1 if nt32_rows is None else int(nt32_rows),
+                                                          -1 if nt32_rows_train is None else int(nt32_rows_train)),
+                        "sdrm_debug_set_nt32_rows")
+        return self
+
     # ------------------------------------------------------------------ parameters
     def set_params(self, flat):
         flat = self._dev(flat, torch.float32).reshape(-1)

@@ -43,11 +43,7 @@ def engine_cls():
 def sampler_path(request):
     """Narrow nets (padded widths <= 64) sample through the persistent LDS-resident kernel (csrc/skinny.h) by
     default; run every sampling parity test through it and through the general per-layer GEMM path."""
-    from sdrm_amd import _lib
-    lib = _lib.load()
-    lib.sdrm_debug_set_skinny(1 if request.param == "skinny" else 0)
-    yield request.param
-    lib.sdrm_debug_set_skinny(1)
+    return request.param == "skinny"
 
 
 def per_tensor(flat, dims):
@@ -70,7 +66,6 @@ def test_mfma_gemm_variants(engine_cls, variant, shape, tile):
     from sdrm_amd import _lib
     import ctypes as C
     lib = _lib.load()
-    lib.sdrm_debug_set_tile(tile)
     M, N, K = shape
     if variant == 2:
         M, K = (K // 32) * 32, ((M + 127) // 128) * 128
@@ -87,9 +82,8 @@ def test_mfma_gemm_variants(engine_cls, variant, shape, tile):
     dA = torch.from_numpy(A.astype(np.float32)).cuda()
     dB = torch.from_numpy(B.astype(np.float32)).cuda()
     dC = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-    rc = lib.sdrm_debug_gemm(variant, C.c_void_p(dA.data_ptr()), C.c_void_p(dB.data_ptr()), C.c_void_p(dC.data_ptr()),
+    rc = lib.sdrm_debug_gemm(variant, tile, C.c_void_p(dA.data_ptr()), C.c_void_p(dB.data_ptr()), C.c_void_p(dC.data_ptr()),
                              M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    lib.sdrm_debug_set_tile(-1)
     assert rc == 0
     torch.cuda.synchronize()
     got = dC.cpu().numpy()
@@ -176,7 +170,7 @@ def test_sampling_golden(engine_cls, golden, sampler_path):
         pf = f"c{ci}_"
         L, W, T, H = (int(v) for v in g[pf + "dims"])
         nd = np.float32(g[pf + "nd"])
-        e = engine_cls(L, W, T, H, 8)
+        e = engine_cls(L, W, T, H, 8).debug_set(skinny=sampler_path)
         e.set_params(g[pf + "flat"])
         n = g[pf + "full_xT"].shape[0]
         full = e.sample(n, nd=float(nd), xT=g[pf + "full_xT"], z=g[pf + "full_rawz"] * nd, keep=g[pf + "full_masks"])
@@ -284,31 +278,25 @@ def test_narrow_net_train_paths_agree(engine_cls, dims):
     """Nets with widths <= 64 run their train forward and dgrad chain in the fused kernels of csrc/skinny_train.h
     (EXPLICIT and PHILOX staging); the general per-layer GEMM path must give the same step: P/S/Q, loss, every
     gradient tensor, the parameters after Adam.  Same arithmetic, different summation order: 2e-5 normwise."""
-    from sdrm_amd import _lib
-    lib = _lib.load()
     L, W, T, H, B = dims
     init = synth.flatten_params(synth.init_params(L, W, T, H, seed=16), H)
     x0 = synth.synth_latents(B, L, seed=17)
     eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=18)
     out = {}
-    try:
-        for path in (1, 0):
-            lib.sdrm_debug_set_skinny(path)
-            for mode in ("explicit", "philox"):
-                e = engine_cls(L, W, T, H, B)
-                e.set_params(init)
-                if mode == "explicit":
-                    e.train_forward(x0, noise=eps, t=t, keep=keep)
-                else:
-                    e.train_forward(x0, seed=77, step=5, nd=0.9, row0=3)
-                loss = float(e.train_backward().cpu())
-                psq = e.train_outputs(B).cpu().numpy()
-                grads = e.get_grads().cpu().numpy()
-                e.adam_step(1e-5)
-                out[(path, mode)] = (loss, psq, grads, e.get_params().cpu().numpy())
-                e.close()
-    finally:
-        lib.sdrm_debug_set_skinny(1)
+    for path in (1, 0):
+        for mode in ("explicit", "philox"):
+            e = engine_cls(L, W, T, H, B).debug_set(skinny=path)
+            e.set_params(init)
+            if mode == "explicit":
+                e.train_forward(x0, noise=eps, t=t, keep=keep)
+            else:
+                e.train_forward(x0, seed=77, step=5, nd=0.9, row0=3)
+            loss = float(e.train_backward().cpu())
+            psq = e.train_outputs(B).cpu().numpy()
+            grads = e.get_grads().cpu().numpy()
+            e.adam_step(1e-5)
+            out[(path, mode)] = (loss, psq, grads, e.get_params().cpu().numpy())
+            e.close()
     for mode in ("explicit", "philox"):
         (l1, p1, g1, w1), (l0, p0, g0, w0) = out[(1, mode)], out[(0, mode)]
         assert abs(l1 - l0) <= 2e-5 * abs(l0), (mode, l1, l0)
@@ -351,7 +339,7 @@ def test_philox_mode_sampling(engine_cls, multires, sampler_path):
     L, W, T, H, n = 37, 40, 12, 2, 19
     seed, call_id, nd, row0 = 99, 5, 0.9, 300
     init = synth.init_params(L, W, T, H, seed=8)
-    e = engine_cls(L, W, T, H, n)
+    e = engine_cls(L, W, T, H, n).debug_set(skinny=sampler_path)
     e.set_params(synth.flatten_params(init, H))
     res = e.sample(n, nd=nd, multires=multires, seed=seed, call_id=call_id, row0=row0, return_Tj=multires)
     xT, z, keep, Tj = pr.sample_randoms(seed, call_id, row0, n, L, T, nd, multires)

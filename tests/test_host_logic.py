@@ -14,15 +14,61 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cabi_exports_every_declared_symbol():
-    """The library loads (no GPU needed) and exports exactly what include/sdrm_hip.h declares."""
-    header = open(os.path.join(REPO, "include", "sdrm_hip.h")).read()
-    declared = set(re.findall(r"\b(sdrm_[a-z_0-9]+)\s*\(", header))
-    declared -= {"sdrm_engine"}
+    """The library loads (no GPU needed) and exports exactly what include/sdrm_hip.h (the boundary) and
+    include/sdrm_hip_debug.h (test / tuning hooks) declare; no debug hook sits in the public header."""
+    declared = set()
+    for name in ("sdrm_hip.h", "sdrm_hip_debug.h"):
+        header = open(os.path.join(REPO, "include", name)).read()
+        found = set(re.findall(r"\b(sdrm_[a-z_0-9]+)\s*\(", header)) - {"sdrm_engine"}
+        if name == "sdrm_hip.h":
+            assert not [f for f in found if f.startswith("sdrm_debug_")], "debug hooks belong in sdrm_hip_debug.h"
+        else:
+            assert all(f.startswith("sdrm_debug_") for f in found), found
+        declared |= found
     lib = _lib.load()
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert hasattr(lib, name), f"{name} declared in a header but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert b"gfx950" in lib.sdrm_build_info()
+
+
+def test_binary_is_bound_to_its_sources(tmp_path, monkeypatch):
+    """The loaded library carries the SHA-256 of csrc/ + include/; touching a source makes the loader see a stale binary
+    (and rebuild it), whatever the file times say."""
+    from sdrm_amd import _build
+    lib = _lib.load()
+    assert lib.sdrm_source_hash().decode() == _build.source_hash() == _build.binary_hash()
+    assert _build.source_hash()[:16].encode() in lib.sdrm_build_info()
+    assert not _build.is_stale()
+    # a copy of the source tree with one edited header: the same binary is stale against it
+    src, inc = tmp_path / "csrc", tmp_path / "include"
+    src.mkdir(), inc.mkdir()
+    for f in _build.source_files():
+        dst = (src if os.path.dirname(f) == _build.SRC_DIR else inc) / os.path.basename(f)
+        dst.write_bytes(open(f, "rb").read())
+    monkeypatch.setattr(_build, "SRC_DIR", str(src))
+    monkeypatch.setattr(_build, "INC_DIR", str(inc))
+    assert not _build.is_stale()
+    with open(src / "philox.h", "ab") as f:
+        f.write(b"\n// touched\n")
+    os.utime(src / "philox.h", (0, 0))              # an OLD file time must not hide the edit
+    assert _build.is_stale()
+    # load() on a stale binary rebuilds (here: into a scratch path, from the edited copy) or refuses
+    monkeypatch.setattr(_build, "LIB_PATH", str(tmp_path / "libsdrm_hip.so"))
+    monkeypatch.setattr(_lib, "_LIB", None)
+    with pytest.raises(RuntimeError, match="is missing"):
+        _lib.load(build_if_missing=False)
+    (tmp_path / "libsdrm_hip.so").write_bytes(open(os.path.join(REPO, "sdrm_amd", "libsdrm_hip.so"), "rb").read())
+    with pytest.raises(RuntimeError, match="different sources"):
+        _lib.load(build_if_missing=False)
+    # the edited header sits two levels below its include/ (csrc/x.hip includes "../../include/sdrm_hip.h"): mirror that
+    deep = tmp_path / "a" / "csrc"
+    deep.mkdir(parents=True)
+    for f in os.listdir(src):
+        (deep / f).write_bytes((src / f).read_bytes())
+    monkeypatch.setattr(_build, "SRC_DIR", str(deep))
+    rebuilt = _lib.load()
+    assert rebuilt.sdrm_source_hash().decode() == _build.source_hash() != lib.sdrm_source_hash().decode()
 
 
 def test_cabi_rejects_bad_arguments_without_a_gpu():

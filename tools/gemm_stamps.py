@@ -5,11 +5,10 @@ import os
 lib = C.CDLL(os.environ.get("STAMPLIB", "tools/libsdrm_stamps.so"))
 lib.sdrm_debug_gemm_stamps.restype = C.c_int
 for cfg in [int(c) for c in os.environ.get("CFGS", "0,1").split(",")]:
-    lib.sdrm_debug_set_tile(cfg)
     for (v, M, N, K) in [(0, 24576, 352, 352), (0, 5440, 352, 352), (0, 2720, 352, 352), (0, 1344, 352, 352)]:
         mb = 8192
         buf = (C.c_ulonglong * (4 * mb))()
-        nb = lib.sdrm_debug_gemm_stamps(v, M, N, K, buf, mb)
+        nb = lib.sdrm_debug_gemm_stamps(v, cfg, M, N, K, buf, mb)
         a = np.frombuffer(buf, dtype=np.uint64).reshape(mb, 4)[:nb].astype(np.int64)
         pro, loop, epi = a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2]
         x0 = a[0::8]                                   # blocks of XCD 0 (every XCD has its own counter base)

@@ -31,9 +31,8 @@ SHAPES = [  # (variant, M, N, K, label)    variant 0: A[M,K]*B[N,K]^T   1: A[M,K
 
 
 def run(variant, M, N, K, cfg, reps=50):
-    lib.sdrm_debug_set_tile(cfg)
     us = C.c_float()
-    rc = lib.sdrm_debug_gemm_time(variant, M, N, K, reps, C.byref(us), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    rc = lib.sdrm_debug_gemm_time(variant, cfg, M, N, K, reps, C.byref(us), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     return us.value, 2.0 * M * N * K / us.value / 1e6
 
@@ -49,4 +48,3 @@ if __name__ == "__main__":
             except AssertionError as exc:
                 row.append(f"cfg{cfg}: n/a({exc})")
         print("  ".join(row), flush=True)
-    lib.sdrm_debug_set_tile(-1)
