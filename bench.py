@@ -15,6 +15,13 @@ train:sample mix cyclically.  Randomness is the engine's Philox mode.  N>1: the 
 users are sharded over ranks (strong scaling: the job is fixed), RCCL all-reduce of 5 loss scalars and
 of the flat gradient per train step, no communication while sampling.
 
+Timing protocol (warm-up, then the median of 5 repeats): an untimed pre-heat of one whole job cycle
+(93 steps: clocks, caches, every kernel variant of the mix loaded) plus the --warmup steps, then the --steps window is
+timed FIVE times back to back, each window bracketed by barrier + device sync on both sides and reduced with MAX over
+ranks; `value` / `ms_per_step` are the MEDIAN window, `window_min_ms` / `window_max_ms` the extremes.  A separate,
+untimed-for-throughput pass records HIP events around every GEMM launch (on the launch stream) for `roofline`; it runs
+at least two job cycles so that the dominant class is averaged over >= 30 launches whatever --steps is.
+
 Prints ONE JSON line on rank 0."""
 from __future__ import annotations
 
@@ -101,9 +108,9 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(wl, seconds_budget=25.0):
-    """The CPU oracle (torch CPU ops, all host cores) on the same step mix: one whole job cycle if it
-    fits the budget, else a proportional prefix."""
+def cpu_baseline(wl, min_seconds=10.0, max_seconds=30.0):
+    """The CPU oracle (torch CPU ops, all host cores) on the same step mix: whole job cycles until at least
+    `min_seconds` of CPU work have been timed, or the prefix of the walk that fits `max_seconds` on a slow host."""
     from oracle import sdrm_oracle as orc
     L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
     cores = host_cores()
@@ -117,7 +124,8 @@ def cpu_baseline(wl, seconds_budget=25.0):
     done = {"train": 0, "sample": 0}
     i = T
     t0 = time.perf_counter()
-    for k in range(cycle):
+    k = 0
+    while True:
         if is_train(k, n_train, cycle):
             eps = torch.randn(B, L, generator=g) * wl["nd"]
             t = torch.randint(1, T + 1, (B,), generator=g)
@@ -131,13 +139,15 @@ def cpu_baseline(wl, seconds_budget=25.0):
             x = orc.reverse_update(x, eps_hat, z, i, o.beta, o.alpha, o.alphabar)
             i = i - 1 if i > 1 else T
             done["sample"] += 1
-        if time.perf_counter() - t0 > seconds_budget and done["train"] >= 2 and done["sample"] >= 10:
+        k += 1
+        el = time.perf_counter() - t0
+        if (k % cycle == 0 and el >= min_seconds) or (el > max_seconds and done["train"] >= 2 and done["sample"] >= 10):
             break
     dt = time.perf_counter() - t0
     steps = done["train"] + done["sample"]
     return {"value": steps / dt, "unit": "denoising-steps/s", "cores": cores, "kind": "port",
             "sample": f"{done['train']} train steps (B={B}) + {done['sample']} reverse-sampling steps (n={n}) of the "
-                      f"same 15:78 mix, oracle/sdrm_oracle.py on torch CPU ops, {cores} threads, {dt:.1f} s"}
+                      f"same 15:78 mix ({k / cycle:.2f} job cycles), oracle/sdrm_oracle.py on torch CPU ops, {cores} threads, {dt:.1f} s"}
 
 
 OTHER = {   # BASELINE.json configs besides the benched one (README hyper-parameters)
@@ -147,77 +157,141 @@ OTHER = {   # BASELINE.json configs besides the benched one (README hyper-parame
 }
 
 
+HBM_ACHIEVABLE_TBS = 6.3   # achievable HBM stream rate the byte roofline is priced against
+
+
+def train_bytes(B, L, W, T, H):   # section 8d minimum: x0 + eps in, 6 passes over the P parameters (p, m, v read + write); PHILOX: no masks
+    return 2.0 * B * L * 4 + 6.0 * synth.param_count(L, W, T, H) * 4
+
+
+def sample_bytes(n, L):           # PHILOX mode: x read + x write
+    return 2.0 * n * L * 4
+
+
 def other_configs():
+    """The other BASELINE.json configs (parity-test cases, not the headline): steps/s, kernel launches per step and the
+    section-8d roofline time max(flops / 157.3 TF, bytes / 6.3 TB/s) beside the measured step time.  These are latency
+    bound (2-164 us of roofline time in 5-17 launches), so `frac` says how far the launch chain is from the arithmetic."""
     from sdrm_amd.engine import Engine
     res = {}
     for name, c in OTHER.items():
-        eng = Engine(c["L"], c["W"], c["T"], c["H"], max_rows=max(c["B"], c["n"]))
-        eng.set_params(synth.flatten_params(synth.init_params(c["L"], c["W"], c["T"], c["H"], seed=1), c["H"]))
-        x0 = torch.from_numpy(synth.synth_latents(c["B"], c["L"], seed=0)).cuda()
+        L, W, T, H, B, n = c["L"], c["W"], c["T"], c["H"], c["B"], c["n"]
+        eng = Engine(L, W, T, H, max_rows=max(B, n))
+        eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
+        x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)).cuda()
         entry = {}
         for kind in ("train", "sample_full", "sample_multires"):
             if kind == "train":
                 fn, reps = (lambda: eng.train_step(x0, 1e-5, seed=1, step=3)), 100
+                roof_us = max(train_flops(B, L, T, H) / (PEAK_FP32_TFLOPS * 1e12), train_bytes(B, L, W, T, H) / (HBM_ACHIEVABLE_TBS * 1e12)) * 1e6
             else:
-                eng.sample_begin(c["n"], seed=2, call_id=1, multires=(kind == "sample_multires"))
-                left = [c["T"]]
+                multires = kind == "sample_multires"
+                eng.sample_begin(n, seed=2, call_id=1, multires=multires)
 
                 def fn():
                     if eng.sample_steps(1) == 0:
                         eng.sample_end()
-                        eng.sample_begin(c["n"], seed=2, call_id=1, multires=(kind == "sample_multires"))
-                reps = 2 * c["T"]
-            for _ in range(5):
-                fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            entry[kind + "_steps_per_s"] = round(reps / (time.perf_counter() - t0), 1)
+                        eng.sample_begin(n, seed=2, call_id=1, multires=multires)
+                reps = 2 * T
+                rows = n / 2.0 if multires else n     # multi-resolution: on average half the rows are active per step
+                roof_us = max(sample_flops(rows, L, T, H) / (PEAK_FP32_TFLOPS * 1e12), sample_bytes(rows, L) / (HBM_ACHIEVABLE_TBS * 1e12)) * 1e6
+            windows = []
+            for w in range(6):       # first window = warm-up, then the median of 5
+                torch.cuda.synchronize()
+                l0, t0 = eng.launch_count(), time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                windows.append((time.perf_counter() - t0, eng.launch_count() - l0))
+            dt = float(np.median([w[0] for w in windows[1:]]))
+            step_us = dt / reps * 1e6
+            entry[kind] = {"steps_per_s": round(reps / dt, 1), "step_us": round(step_us, 2),
+                           "launches_per_step": round(windows[-1][1] / reps, 2),
+                           "roofline_us": round(roof_us, 2), "frac": round(roof_us / step_us, 4)}
+            if kind != "train":
+                while eng.sample_steps(T) != 0:
+                    pass
+                eng.sample_end()
         eng.close()
         res[name] = entry
     return res
 
 
-def pmc_traffic(kernel_class: str):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*pmc_traffic.json,
-    made by tools/pmc_summary.py from two separate `rocprofv3 --pmc` runs of this same command; gfx950
-    FETCH_SIZE correction applied there).  None if no such file travels with the repo."""
+def _profile_file(pattern: str):
+    """Newest committed profile of that kind (profiles/rNN_*; names sort by round)."""
     import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def pmc_traffic(kernel_class: str, lib_hash: str):
+    """HBM bytes per launch of the dominant kernel REPLAYED from the committed PMC passes (profiles/*pmc_traffic.json,
+    made by tools/pmc_summary.py from two separate `rocprofv3 --pmc` runs of this same command; gfx950 FETCH_SIZE
+    correction applied there) - counters cannot be read inside an unprofiled run.  Returns (bytes or None, provenance):
+    the value is dropped when the file was collected from other kernel sources than the library loaded now."""
     import re
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_traffic.json")))
+    path = _profile_file("*pmc_traffic.json")
     m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
-    if not files or not m:
-        return None, None
+    if not path or not m:
+        return None, {"file": None}
+    data = json.load(open(path))
+    src = {"file": os.path.basename(path), "git_head": data.get("git_head"), "source_hash": (data.get("source_hash") or "")[:16] or None,
+           "matches_loaded_library": bool(data.get("source_hash")) and data.get("source_hash") == lib_hash}
+    if not src["matches_loaded_library"]:
+        return None, src
     needle = ", " + ", ".join(m.groups()) + ">("
-    data = json.load(open(files[-1]))
     for name, v in data.get("kernels", {}).items():
         if needle in name:
             # the same template serves train launches (24576 rows: the largest grid) and sampling launches
             rows = sorted(v.get("by_grid", []), key=lambda r: r["grid_size"])
             if rows:
                 pick = rows[0] if kernel_class.startswith("sample") else rows[-1]
-                return pick["hbm_bytes_per_launch"], os.path.basename(files[-1])
-            return v["hbm_bytes_per_launch_mean"], os.path.basename(files[-1])
-    return None, None
+                return pick["hbm_bytes_per_launch"], src
+            return v["hbm_bytes_per_launch_mean"], src
+    return None, src
 
 
-def pmc_mfma_busy(kernel_class: str):
-    """Matrix-pipe busy cycles per SIMD and launch of the dominant kernel from the committed SQ counter pass
-    (profiles/*pmc_sq.json, made by tools/pmc_sq.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...` of this command)."""
-    import glob
+def pmc_mfma_busy(kernel_class: str, lib_hash: str):
+    """Matrix-pipe busy cycles per SIMD and launch of the dominant kernel, replayed from the committed SQ counter pass
+    (profiles/*pmc_sq.json, made by tools/pmc_sq.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...` of this command);
+    None when that pass belongs to other kernel sources."""
     import re
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*pmc_sq.json")))
+    path = _profile_file("*pmc_sq.json")
     m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
-    if not files or not m:
+    if not path or not m:
+        return None
+    data = json.load(open(path))
+    if not data.get("source_hash") or data.get("source_hash") != lib_hash:
         return None
     needle = ", " + ", ".join(m.groups()) + ">("
-    for name, rows in json.load(open(files[-1])).get("kernels", {}).items():
+    for name, rows in data.get("kernels", {}).items():
         if needle in name and rows:
             rows = sorted(rows, key=lambda r: r["grid_size"])
             return (rows[0] if kernel_class.startswith("sample") else rows[-1])["mfma_busy_per_simd_cycles"]
     return None
+
+
+def pick_windows(K: int, cycle: int, at_least: int = 5, at_most: int = 24) -> int:
+    """Number of timed K-step windows: the smallest count >= at_least whose total is closest to whole job cycles."""
+    best, best_err = at_least, None
+    for w in range(max(1, at_least), max(at_least, at_most) + 1):
+        tot = w * K
+        err = abs(tot - round(tot / cycle) * cycle) / tot
+        if best_err is None or err < best_err - 1e-12:
+            best, best_err = w, err
+    return best
+
+
+def combine_windows(window_ms, window_trains, K):
+    """(seconds per K-step window, {"train": t, "sample": s} average step counts of a window): median duration within
+    each train-step-count class, classes weighted by their number of windows."""
+    classes = {}
+    for ms, n_tr in zip(window_ms, window_trains):
+        classes.setdefault(n_tr, []).append(ms)
+    n = len(window_ms)
+    ms = sum(len(v) * float(np.median(v)) for v in classes.values()) / n
+    trains = sum(len(v) * k for k, v in classes.items()) / n
+    return ms * 1e-3, {"train": trains, "sample": K - trains}
 
 
 def main():
@@ -226,8 +300,9 @@ def main():
     ap.add_argument("--steps", type=int, default=186)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--other-configs", action="store_true",
-                    help="also time the other BASELINE.json configs (train and sample steps/s each); extra fields only")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra legs on the other BASELINE.json configs (steps/s, launches per step, roofline time)")
+    ap.add_argument("--windows", type=int, default=5, help="least number of timed repeats of the --steps window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
@@ -267,24 +342,43 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- pre-heat: one whole job cycle whatever --warmup says (a 5-step warm-up leaves the first timed train steps
+    # cold: round 1's driver line read 20 % under the warm numbers), then the caller's warm-up steps
+    n_cycle = wl["epochs"] * wl["batches_per_epoch"] + T
+    for _ in range(n_cycle + args.warmup):
         job.step()
-    barrier()
-    t0 = time.perf_counter()
-    kinds = {"train": 0, "sample": 0}
-    for _ in range(args.steps):
-        kinds[job.step()] += 1
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.cpu())
+    # ---- the --steps window, timed several times back to back along the job's cyclic walk; each window: barrier + sync,
+    # EXACTLY K steps, barrier + sync, MAX over ranks.  A window shorter than a job cycle holds a whole number of train
+    # steps (20 steps: 3 or 4, i.e. 15 % or 20 % against the job's 16.1 %), so windows are only comparable within their
+    # train-step count: the figure reported is the MEDIAN window of each composition class, the classes weighted by how
+    # often the walk produces them, over a number of windows that covers whole job cycles - robust like a median,
+    # unbiased in the train:sample mix whatever --steps is.
+    n_windows = pick_windows(args.steps, n_cycle, args.windows)
+    window_ms, window_trains = [], []
+    for w in range(n_windows):
+        barrier()
+        t0 = time.perf_counter()
+        n_tr = 0
+        for _ in range(args.steps):
+            n_tr += job.step() == "train"
+        barrier()
+        dt_w = time.perf_counter() - t0
+        tmax = torch.tensor([dt_w], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        window_ms.append(float(tmax.cpu()) * 1e3)
+        window_trains.append(n_tr)
+    dt, kinds = combine_windows(window_ms, window_trains, args.steps)
 
-    # ---- second, untimed-for-throughput pass of the same K steps with HIP events around every GEMM launch
-    eng.profile_begin(capacity=args.steps * 16)
-    for _ in range(args.steps):
-        job.step()
+    # ---- second, untimed-for-throughput pass with HIP events around every GEMM launch: at least two job cycles, so the
+    # dominant class (one batched weight-gradient launch per train step) is averaged over >= 30 launches
+    prof_steps = max(args.steps, 2 * n_cycle)
+    eng.profile_begin(capacity=prof_steps * 16)
+    l0 = eng.launch_count()
+    prof_kinds = {"train": 0, "sample": 0}
+    for _ in range(prof_steps):
+        prof_kinds[job.step()] += 1
+    launches_total = eng.launch_count() - l0
     prof = eng.profile_end()
 
     # ---- separate train-only / sample-only rates (extra information, not `value`)
@@ -313,12 +407,15 @@ def main():
         if dom:
             name, (ms, launches, flops) = dom
             achieved = flops / (ms * 1e-3) / 1e12
-            traffic, src = pmc_traffic(name)
+            lib_hash = eng.lib.sdrm_source_hash().decode()
+            traffic, src = pmc_traffic(name, lib_hash)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": src,
+                    "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)",
+                    "traffic_measured_in_run": False, "traffic_source": src,
                     "avg_launch_us": round(ms * 1e3 / launches, 2), "launches": launches,
-                    "mfma_busy_cycles_per_simd": pmc_mfma_busy(name),
+                    "event_pass_steps": prof_steps,
+                    "mfma_busy_cycles_per_simd": pmc_mfma_busy(name, lib_hash),
                     "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs per launch (PMC pass); divide by avg_launch_us x "
                                       "shader clock (~2.1 GHz in kernels this short, tools/mfma_probe.hip) for the pipe utilisation",
                     "algorithmic_flops_per_launch": flops / launches,
@@ -330,18 +427,24 @@ def main():
             "metric": "denoising-steps/sec (train+sample) on ML-1M latents", "value": round(args.steps / dt, 2),
             "unit": "denoising-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "windows": len(window_ms), "window_ms": [round(v, 3) for v in window_ms], "window_train_steps": window_trains,
+            "window_min_ms": round(min(window_ms), 3), "window_max_ms": round(max(window_ms), 3),
+            "window_rule": "median per train-step-count class, classes weighted by frequency; windows span whole job cycles",
+            "preheat_steps": n_cycle,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "latent": L, "width": W, "timesteps": T, "hidden_layers": H,
                        "global_batch": B, "n_sample": n, "step_mix": f"{n_train} train : {T} sample per job cycle",
-                       "timed_train_steps": kinds["train"], "timed_sample_steps": kinds["sample"],
+                       "timed_train_steps": round(kinds["train"], 3), "timed_sample_steps": round(kinds["sample"], 3),
                        "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
                        "collectives": (f"{args.backend}: all-reduce of 5 f64 loss sums + flat f32 gradient per train step"
                                        if world > 1 else "none")},
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
+            "launches_per_step": round(launches_total / prof_steps, 2),
+            "library_source_hash": eng.lib.sdrm_source_hash().decode()[:16],
             "roofline": roof,
         }
-        if world == 1 and args.other_configs:
+        if world == 1 and not args.no_other_configs:
             out["other_configs"] = other_configs()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)

@@ -185,6 +185,9 @@ int sdrm_profile_classes(void);
 const char* sdrm_profile_name(int cls);
 int sdrm_profile_get(const sdrm_engine* e, int cls, double* total_ms, int64_t* launches, double* flops);
 
+/* Kernel launches issued through this handle since sdrm_create (memcpy / memset nodes not counted): bench.py reports
+ * launches per step beside the roofline of the latency-bound configurations. */
+int64_t sdrm_launch_count(const sdrm_engine* e);
 /* Name of the GEMM kernel variant family in use and tile geometry, as a static string. */
 const char* sdrm_build_info(void);
 /* Hex SHA-256 of the sources this binary was compiled from (sdrm_amd/csrc/ and include/, as sdrm_amd/_build.py hashes

@@ -23,8 +23,8 @@ enum { SDRM_TILE_AUTO = -1, SDRM_TILE_COUNT = 5 };
 
 /* Forces the GEMM tile shape of every launch of this engine (SDRM_TILE_AUTO = automatic: 64x64x16, or 32x32x32 for NT
  * launches of at most `nt32` rows, see sdrm_debug_set_nt32_rows); also env SDRM_TILE, read by sdrm_create.  Refused
- * (SDRM_ERR_STATE) between a train forward and its backward and inside a sampling call: the slope partial layout of a
- * backward is fixed by the tile its forward chose. */
+ * (SDRM_ERR_STATE) between sdrm_train_backward_begin and _finish and inside a sampling call; a train forward still
+ * waiting for its backward is dropped (the slope partial layout of a backward is fixed by the tile of its forward). */
 int sdrm_debug_set_tile(sdrm_engine* e, int cfg);
 /* Row thresholds of the automatic tile choice: NT launches of at most max_rows rows (sampling, plain forward; default
  * 4096) / max_rows_train stacked rows (train step; default 8192) run on the 32x32x32 tile.  A negative value leaves

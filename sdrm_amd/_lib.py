@@ -59,6 +59,7 @@ SIGNATURES = {
     "sdrm_profile_classes": (c_int, []),
     "sdrm_profile_name": (C.c_char_p, [c_int]),
     "sdrm_profile_get": (c_int, [c_void_p, c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
+    "sdrm_launch_count": (c_int64, [c_void_p]),
     "sdrm_build_info": (C.c_char_p, []),
     "sdrm_csr_rows_to_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),

@@ -90,6 +90,7 @@ struct sdrm_engine {
   bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
+  mutable int64_t n_launches = 0;    // kernel launches issued through this handle since sdrm_create
   uint64_t params_version = 0;       // bumped whenever the parameters change (set_params, Adam)
   uint64_t smp_b0_version = 0;       // parameters the sampler's bias table B0tab was built from
   struct SampleStateT {
@@ -138,6 +139,13 @@ namespace {
       (e)->err = std::string(#call) + ": " + hipGetErrorString(_st);                       \
       return SDRM_ERR_HIP;                                                                 \
     }                                                                                      \
+  } while (0)
+
+// every kernel launch goes through here: the handle counts them (sdrm_launch_count: launches per step for bench.py)
+#define SDRM_LAUNCH(eng, ...)                      \
+  do {                                             \
+    if (eng) ++(eng)->n_launches;                  \
+    hipLaunchKernelGGL(__VA_ARGS__);               \
   } while (0)
 
 int fail(sdrm_engine* e, int code, const std::string& msg) {
@@ -220,7 +228,7 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
     hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
     if (st0 != hipSuccess) return st0;
   }
-  hipLaunchKernelGGL((gemm_kernel<Cfg, LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
+  SDRM_LAUNCH(pr.e, (gemm_kernel<Cfg, LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
   hipError_t rc = hipGetLastError();
   if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
   return rc;
@@ -310,7 +318,7 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
     if (st0 != hipSuccess) return st0;
   }
-  hipLaunchKernelGGL((gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_PRELU, EPI_SLAB>), dim3((unsigned)grid),
+  SDRM_LAUNCH(e, (gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_PRELU, EPI_SLAB>), dim3((unsigned)grid),
                      dim3(NTHREADS), 0, st, b);
   hipError_t rc = hipGetLastError();
   if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
@@ -396,7 +404,7 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
   for (int k = 0; k < tab.n_adam; ++k) biggest = std::max<int64_t>(biggest, (int64_t)tab.j[k].rows * tab.j[k].cols);
   const int gx = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (biggest + 511) / 512));
   dim3 grid(gx, tab.n_adam);
-  hipLaunchKernelGGL(k_adam, grid, dim3(256), 0, st, tab, a);
+  SDRM_LAUNCH(e, k_adam, grid, dim3(256), 0, st, tab, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -411,7 +419,7 @@ EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
 
 int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
   const EmbTabArgs a = emb_args(e, for_sampling);
-  hipLaunchKernelGGL(k_emb_tables, dim3(e->T + 1), dim3(256), 2 * e->T * sizeof(float), st, a);
+  SDRM_LAUNCH(e, k_emb_tables, dim3(e->T + 1), dim3(256), 2 * e->T * sizeof(float), st, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -438,8 +446,8 @@ int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hi
   dim3 grid(ka.MP / 16), block(64 * (NL > NW ? NL : NW));
 #define SKT_LAUNCH(nl, nw)                                                                         \
   do {                                                                                             \
-    if (which == 0) hipLaunchKernelGGL((k_skinny_train_fwd<nl, nw>), grid, block, 0, st, ka);      \
-    else hipLaunchKernelGGL((k_skinny_train_bwd<nl, nw>), grid, block, 0, st, ka);                 \
+    if (which == 0) SDRM_LAUNCH(e, (k_skinny_train_fwd<nl, nw>), grid, block, 0, st, ka);      \
+    else SDRM_LAUNCH(e, (k_skinny_train_bwd<nl, nw>), grid, block, 0, st, ka);                 \
   } while (0)
 #define SKT_ROW(nl)                                 \
   switch (NW) {                                     \
@@ -582,8 +590,9 @@ int sdrm_debug_set_chains(sdrm_engine* e, int chains) {
 
 int sdrm_debug_set_tile(sdrm_engine* e, int cfg) {
   if (!e) return SDRM_ERR_ARG;
-  if (e->fwd_done || e->bwd_begun || e->smp.active)
-    return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_tile: a train step or a sampling call is in progress");
+  if (e->bwd_begun || e->smp.active)
+    return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_tile: a two-call backward or a sampling call is in progress");
+  e->fwd_done = false;   // the slope-partial layout of a backward is fixed by its forward's tile: a pending forward is dropped
   e->tune.force_cfg = cfg;
   return SDRM_OK;
 }
@@ -804,10 +813,10 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     if (rc) return rc;
     LossArgs la{};
     la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
-    hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
+    SDRM_LAUNCH(e, k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
     HIP_TRY(e, hipGetLastError());
     if (!e->fold_sums) {
-      hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
                          (double)B * (double)e->L, sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
@@ -828,7 +837,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     pa.emb_row0 = B + (MP - 3 * B);
     pa.emb_blocks = e->T + 1;
     const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
-    hipLaunchKernelGGL(k_prep_train, dim3(pa.emb_blocks + main_blocks), dim3(256), 2 * e->T * sizeof(float), st, pa);
+    SDRM_LAUNCH(e, k_prep_train, dim3(pa.emb_blocks + main_blocks), dim3(256), 2 * e->T * sizeof(float), st, pa);
     HIP_TRY(e, hipGetLastError());
   }
   {
@@ -848,10 +857,10 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   }
   LossArgs la{};
   la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
-  hipLaunchKernelGGL(k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
+  SDRM_LAUNCH(e, k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
   HIP_TRY(e, hipGetLastError());
   if (!e->fold_sums) {
-    hipLaunchKernelGGL(k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
+    SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
                        (double)B * (double)e->L, sums ? sums : e->sums);
     HIP_TRY(e, hipGetLastError());
   }
@@ -878,7 +887,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   sa.part = e->loss_part; sa.nblk = LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
   {
     dim3 grid((unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256));
-    hipLaunchKernelGGL(k_loss_seed, grid, dim3(256), 0, st, sa);
+    SDRM_LAUNCH(e, k_loss_seed, grid, dim3(256), 0, st, sa);
     HIP_TRY(e, hipGetLastError());
   }
   int S0, SH, SO, kc0, kcH, kcO;
@@ -975,7 +984,7 @@ int backward_finalize(sdrm_engine* e, float* gout, int which, hipStream_t st) {
     const bool second = tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P;
     if ((second && (which & BUCKET_SECOND)) || (!second && (which & BUCKET_FIRST))) sel.j[sel.n++] = tab.j[j];
   }
-  hipLaunchKernelGGL(k_grad_finalize, dim3(512, sel.n), dim3(256), 0, st, sel);
+  SDRM_LAUNCH(e, k_grad_finalize, dim3(512, sel.n), dim3(256), 0, st, sel);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -987,10 +996,10 @@ int backward_embedding(sdrm_engine* e, float* gout, hipStream_t st) {
   ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = gout;
   ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
   ea.L = e->L; ea.W = e->W; ea.T = e->T;
-  hipLaunchKernelGGL(k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 255) / 256), dim3(1024), 0, st, ea);
+  SDRM_LAUNCH(e, k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 255) / 256), dim3(1024), 0, st, ea);
   HIP_TRY(e, hipGetLastError());
   const int items = e->T * e->T + e->T;
-  hipLaunchKernelGGL(k_emb_bwd2, dim3((items + 63) / 64), dim3(256), 0, st, ea);   // four lanes per output
+  SDRM_LAUNCH(e, k_emb_bwd2, dim3((items + 63) / 64), dim3(256), 0, st, ea);   // four lanes per output
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -1069,7 +1078,7 @@ int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
   if (!e || !psq) return SDRM_ERR_ARG;
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_train_outputs: no forward yet");
-  hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
+  SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
                      e->LP, psq);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
@@ -1089,7 +1098,7 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
   pa.row0 = row0;
   pa.bpr = (e->K0 / 2 + 255) / 256;
   dim3 grid((unsigned)((size_t)pa.bpr * MP));
-  hipLaunchKernelGGL(k_prep_forward, grid, dim3(256), 0, st, pa);
+  SDRM_LAUNCH(e, k_prep_forward, grid, dim3(256), 0, st, pa);
   HIP_TRY(e, hipGetLastError());
   int rc = emb_tables(e, false, st);
   if (rc) return rc;
@@ -1128,7 +1137,7 @@ int sdrm_reverse_step(sdrm_engine* e, float* x, int n, int i, const float* z, co
   if (rc) return rc;
   float c1, sa, sb;
   reverse_coeffs(e, i, c1, sa, sb);
-  hipLaunchKernelGGL(k_reverse_apply, dim3(256), dim3(256), 0, st, x, (const float*)e->Y, e->LP, z, n, e->L, c1, sa, sb);
+  SDRM_LAUNCH(e, k_reverse_apply, dim3(256), dim3(256), 0, st, x, (const float*)e->Y, e->LP, z, n, e->L, c1, sa, sb);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -1137,7 +1146,7 @@ int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const f
                        void* stream) {
   if (!e || !x || !t || !noise || !out || n < 1) return fail(e, SDRM_ERR_ARG, "sdrm_perturb_input: bad argument");
   const int nn = e->T + 1;
-  hipLaunchKernelGGL(k_perturb, dim3(256), dim3(256), 0, (hipStream_t)stream, x, t, noise,
+  SDRM_LAUNCH(e, k_perturb, dim3(256), dim3(256), 0, (hipStream_t)stream, x, t, noise,
                      (const float*)(e->sched + 3 * nn), (const float*)(e->sched + 4 * nn), n, e->L, e->T, out);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
@@ -1210,7 +1219,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   ia.call_id = (uint32_t)call_id; ia.row0 = row0;
   ia.bpr = (e->LP / 4 + 255) / 256;
   dim3 grid((unsigned)((size_t)ia.bpr * MP));
-  hipLaunchKernelGGL(k_sample_init, grid, dim3(256), 0, st, ia);
+  SDRM_LAUNCH(e, k_sample_init, grid, dim3(256), 0, st, ia);
   HIP_TRY(e, hipGetLastError());
   e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, false, false, i_start};
   return SDRM_OK;
@@ -1238,7 +1247,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ka.LPs = e->LP; ka.WPs = e->WP;
       const int NL = (L + 15) / 16, NW = (e->W + 15) / 16;           // tiles with real columns (1..4 each)
       dim3 grid((n + 15) / 16), block(64 * (NL > NW ? NL : NW));   // 16 rows per work-group, one wave per column tile
-#define SKINNY_LAUNCH(nl, nw) hipLaunchKernelGGL((k_skinny_sample<nl, nw>), grid, block, 0, st, ka)
+#define SKINNY_LAUNCH(nl, nw) SDRM_LAUNCH(e, (k_skinny_sample<nl, nw>), grid, block, 0, st, ka)
 #define SKINNY_ROW(nl)                                 \
   switch (NW) {                                        \
     case 1: SKINNY_LAUNCH(nl, 1); break;               \
@@ -1326,7 +1335,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
       ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
       ra.bpr = ((L + 3) / 4 + 255) / 256;
-      hipLaunchKernelGGL(k_reverse_update, dim3((unsigned)((size_t)ra.bpr * rows)), dim3(256), 0, sc, ra);
+      SDRM_LAUNCH(e, k_reverse_update, dim3((unsigned)((size_t)ra.bpr * rows)), dim3(256), 0, sc, ra);
       HIP_TRY(e, hipGetLastError());
     }
   }
@@ -1343,7 +1352,7 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (e->smp.skinny)   // the persistent kernel wrote dense [n,L] rows in original order
     HIP_TRY(e, hipMemcpyAsync(out, e->X, (size_t)e->smp.n * e->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   else
-    hipLaunchKernelGGL(k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
+    SDRM_LAUNCH(e, k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
                        e->smp.n, e->L, (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
   HIP_TRY(e, hipGetLastError());
   e->smp.active = false;
@@ -1366,7 +1375,7 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
   if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
-  hipLaunchKernelGGL(k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
+  SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
                      e->cur_B, e->W, e->WP, out);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
@@ -1380,7 +1389,7 @@ int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t*
   if (b < 1 || n_items < 1 || row0 < 0) return fail(e, SDRM_ERR_SHAPE, "sdrm_csr_rows_to_dense: b < 1, n_items < 1 or row0 < 0");
   FeedArgs a{};
   a.indptr = indptr; a.indices = indices; a.data = data; a.rows = rows; a.row0 = row0; a.b = b; a.n_items = n_items; a.out = out;
-  hipLaunchKernelGGL(k_csr_rows_to_dense, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
+  SDRM_LAUNCH(e, k_csr_rows_to_dense, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
@@ -1412,19 +1421,19 @@ int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uin
     if (r0 > n - 1) r0 = n - 1;
     if (r1 > n - 1) r1 = n - 1;
   }
-  hipLaunchKernelGGL(k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
+  SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
   HIP_TRY(e, hipGetLastError());
   const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
   for (int pass = 0; pass < SEL_PASSES; ++pass) {
-    if (pass == 0) hipLaunchKernelGGL((k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
-    else hipLaunchKernelGGL((k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    if (pass == 0) SDRM_LAUNCH(e, (k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    else SDRM_LAUNCH(e, (k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
     HIP_TRY(e, hipGetLastError());
-    hipLaunchKernelGGL(k_select_pick, dim3(1), dim3(256), 0, st, e->sel, pass, gamma);
+    SDRM_LAUNCH(e, k_select_pick, dim3(1), dim3(256), 0, st, e->sel, pass, gamma);
     HIP_TRY(e, hipGetLastError());
   }
   if (threshold) HIP_TRY(e, hipMemcpyAsync(threshold, &e->sel->threshold, 4, hipMemcpyDeviceToDevice, st));
   if (out) {
-    hipLaunchKernelGGL(k_binarize_ge, dim3(blocks), dim3(256), 0, st, x, n, (const float*)&e->sel->threshold, out);
+    SDRM_LAUNCH(e, k_binarize_ge, dim3(blocks), dim3(256), 0, st, x, n, (const float*)&e->sel->threshold, out);
     HIP_TRY(e, hipGetLastError());
   }
   return SDRM_OK;
@@ -1457,12 +1466,13 @@ int sdrm_rank_metrics(sdrm_engine* e, const float* scores, int U, int I, const i
   const size_t lds = (size_t)I * sizeof(float);
   if (lds > 48 * 1024)
     HIP_TRY(e, hipFuncSetAttribute((const void*)k_rank_metrics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_rank_metrics, dim3(U), dim3(256), lds, (hipStream_t)stream, a);
+  SDRM_LAUNCH(e, k_rank_metrics, dim3(U), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
+int64_t sdrm_launch_count(const sdrm_engine* e) { return e ? e->n_launches : -1; }
 int sdrm_profile_classes(void) { return PC_COUNT; }
 const char* sdrm_profile_name(int cls) { return (cls >= 0 && cls < PC_COUNT) ? kProfNames[cls] : ""; }
 

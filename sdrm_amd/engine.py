@@ -218,6 +218,10 @@ class Engine:
         self._check(self.lib.sdrm_get_preacts(self._h, int(layer), _ptr(out), _stream()), "sdrm_get_preacts")
         return out
 
+    def launch_count(self):
+        """Kernel launches issued through this handle so far (bench.py: launches per step)."""
+        return int(self.lib.sdrm_launch_count(self._h))
+
     # ------------------------------------------------------------------ profiling (bench only)
     def profile_begin(self, capacity=4096):
         self._check(self.lib.sdrm_profile_begin(self._h, int(capacity)), "sdrm_profile_begin")

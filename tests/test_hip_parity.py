@@ -46,6 +46,15 @@ def sampler_path(request):
     return request.param == "skinny"
 
 
+TILES = [-1, 0, 4]   # automatic; forced 64x64x16 (32-wide MFMA); forced 32x32x32 (16-wide MFMA): every step-level test
+                     # below runs on each, so a size-threshold retune cannot change which kernels the suite covers
+
+
+@pytest.fixture(params=TILES, ids=lambda t: f"tile{t}")
+def tile(request):
+    return request.param
+
+
 def per_tensor(flat, dims):
     L, W, T, H = dims
     shapes = synth.param_shapes(L, W, T, H)
@@ -105,11 +114,11 @@ def test_schedule_golden(engine_cls, golden, T):
     e.close()
 
 
-def test_forward_golden(engine_cls, golden):
+def test_forward_golden(engine_cls, golden, tile):
     g = golden("forward")
     for ci in range(int(g["n_cases"])):
         L, W, T, H = (int(v) for v in g[f"c{ci}_dims"])
-        e = engine_cls(L, W, T, H, 8)
+        e = engine_cls(L, W, T, H, 8).debug_set(tile=tile)
         e.set_params(g[f"c{ci}_flat"])
         for B in (1, 5):
             k = f"c{ci}_B{B}"
@@ -128,7 +137,7 @@ def test_elementwise_golden(engine_cls, golden):
     e.close()
 
 
-def test_train_golden(engine_cls, golden):
+def test_train_golden(engine_cls, golden, tile):
     """The reference's whole train_SDRM() runs replayed through the C ABI: P/S/Q, loss, every
     gradient tensor (shared hidden layer accumulation, Q1), post-Adam parameters across the
     epoch boundary, final Adam moments."""
@@ -139,7 +148,7 @@ def test_train_golden(engine_cls, golden):
         L, W, T, H = dims
         lr0, nd, epochs, nb = g[pf + "hyper"]
         epochs, nb = int(epochs), int(nb)
-        e = engine_cls(L, W, T, H, 16)
+        e = engine_cls(L, W, T, H, 16).debug_set(tile=tile)
         e.set_params(g[pf + "init_flat"])
         for s in range(epochs * nb):
             lr = lr0 * (1 - (s // nb) / epochs)
@@ -164,13 +173,15 @@ def test_train_golden(engine_cls, golden):
         e.close()
 
 
-def test_sampling_golden(engine_cls, golden, sampler_path):
+def test_sampling_golden(engine_cls, golden, sampler_path, tile):
+    if sampler_path and tile != -1:
+        pytest.skip("the persistent narrow-net sampler has no tile choice")
     g = golden("sampling")
     for ci in range(int(g["n_cases"])):
         pf = f"c{ci}_"
         L, W, T, H = (int(v) for v in g[pf + "dims"])
         nd = np.float32(g[pf + "nd"])
-        e = engine_cls(L, W, T, H, 8).debug_set(skinny=sampler_path)
+        e = engine_cls(L, W, T, H, 8).debug_set(skinny=sampler_path, tile=tile)
         e.set_params(g[pf + "flat"])
         n = g[pf + "full_xT"].shape[0]
         full = e.sample(n, nd=float(nd), xT=g[pf + "full_xT"], z=g[pf + "full_rawz"] * nd, keep=g[pf + "full_masks"])
@@ -239,7 +250,7 @@ def engine_branch_masks(e, o, caches, B, kink_tol=2e-5):
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (40, 40, 93, 5, 850), (830, 830, 83, 2, 550),
                                   (50, 70, 5, 0, 33), (100, 100, 198, 3, 129), (340, 340, 78, 1, 2048),
                                   (96, 96, 5, 1, 45000)])   # 135 000 stacked rows: > 4096 slope partials per application
-def test_train_step_vs_oracle(engine_cls, dims):
+def test_train_step_vs_oracle(engine_cls, dims, tile):
     """Full tensors (not checksums) against the CPU oracle at sizes it finishes in seconds.  The oracle
     backward is evaluated with the engine's own PReLU branch choice (verified to differ only at
     pre-activations that are zero within rounding): one such flip alone moves upstream gradients by
@@ -250,7 +261,7 @@ def test_train_step_vs_oracle(engine_cls, dims):
     x0 = synth.synth_latents(B, L, seed=4)
     eps, t, masks = synth.synth_train_randoms(B, L, T, 0.9, seed=5)
     lr = 1e-4
-    e = engine_cls(L, W, T, H, B)
+    e = engine_cls(L, W, T, H, B).debug_set(tile=tile)
     e.set_params(synth.flatten_params(init, H))
     e.train_forward(x0, noise=eps, t=t, keep=masks)
     o = orc.Oracle(L, W, T, H, init)
@@ -332,14 +343,21 @@ def test_philox_mode_train(engine_cls, dims):
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("multires", [False, True])
-def test_philox_mode_sampling(engine_cls, multires, sampler_path):
+def test_philox_mode_sampling(engine_cls, multires, sampler_path, tile, fused):
+    """`fused`: the reverse update stand-alone (0), fused into the out-layer epilogue by the size rule (1) or always (2);
+    with `tile` this reaches both MFMA branches of EPI_TANH_REV whatever the row thresholds are."""
     from oracle import philox_ref as pr
     from oracle import sdrm_oracle as orc
+    if sampler_path and (tile != -1 or fused != 1):
+        pytest.skip("the persistent narrow-net sampler has no tile / fusion choice")
+    if multires and fused != 1:
+        pytest.skip("multi-resolution sampling always uses the stand-alone reverse update")
     L, W, T, H, n = 37, 40, 12, 2, 19
     seed, call_id, nd, row0 = 99, 5, 0.9, 300
     init = synth.init_params(L, W, T, H, seed=8)
-    e = engine_cls(L, W, T, H, n).debug_set(skinny=sampler_path)
+    e = engine_cls(L, W, T, H, n).debug_set(skinny=sampler_path, tile=tile, fused_reverse=fused)
     e.set_params(synth.flatten_params(init, H))
     res = e.sample(n, nd=nd, multires=multires, seed=seed, call_id=call_id, row0=row0, return_Tj=multires)
     xT, z, keep, Tj = pr.sample_randoms(seed, call_id, row0, n, L, T, nd, multires)
@@ -370,6 +388,67 @@ def test_skinny_sampler_vs_oracle(engine_cls, dims, multires):
     ref = orc.Oracle(L, W, T, H, init).sample(xT, z, keep, Tj if multires else None)
     assert close(out, ref.numpy()), rel_max(out.cpu().numpy(), ref.numpy())
     e.close()
+
+
+def test_sampler_follows_parameters_between_calls(engine_cls, tile):
+    """Train steps may run between sdrm_sample_steps calls (bench.py interleaves them).  On the per-layer path the later
+    reverse steps use the new parameters in every layer - including the folded layer-0 bias table b0 + C0[i], which is
+    rebuilt when the parameters moved (a stale table was ADVICE r1) - and a forward waiting for its backward is dropped."""
+    from oracle import sdrm_oracle as orc
+    from sdrm_amd.engine import SdrmError
+    L, W, T, H, n, cut = 96, 80, 10, 1, 50, 6
+    init_a, init_b = synth.init_params(L, W, T, H, seed=41), synth.init_params(L, W, T, H, seed=42)
+    xT, z, keep, _ = synth.synth_sample_randoms(n, L, T, 1.0, seed=43)
+    e = engine_cls(L, W, T, H, n).debug_set(tile=tile)
+    e.set_params(synth.flatten_params(init_a, H))
+    xT_d, z_d, keep_d = (torch.from_numpy(a).cuda() for a in (xT, z, keep))
+    import ctypes as C
+    from sdrm_amd import _lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert e.lib.sdrm_sample_begin(e._h, n, 1.0, 0, _lib.RNG_EXPLICIT, C.c_void_p(xT_d.data_ptr()), C.c_void_p(z_d.data_ptr()),
+                                   C.c_void_p(keep_d.data_ptr()), None, 0, 0, 0, None, st) == 0
+    e._sample_n = n
+    assert e.sample_steps(T - cut) == cut
+    eps, t, masks = synth.synth_train_randoms(n, L, T, 1.0, seed=44)
+    e.train_forward(synth.synth_latents(n, L, seed=45), noise=eps, t=t, keep=masks)
+    e.set_params(synth.flatten_params(init_b, H))
+    assert e.sample_steps(T) == 0
+    with pytest.raises(SdrmError):
+        e.train_backward()          # the sampler ran through the buffers that forward lived in
+    out = e.sample_end()
+    oa, ob = orc.Oracle(L, W, T, H, init_a), orc.Oracle(L, W, T, H, init_b)
+    x = torch.from_numpy(xT).clone()
+    for i in range(T, 0, -1):
+        o = oa if i > cut else ob
+        eps_hat = o.forward(x, torch.full((n,), i, dtype=torch.int64), torch.from_numpy(keep[i]).float())
+        zi = torch.from_numpy(z[i]) if i > 1 else torch.zeros_like(x)
+        x = orc.reverse_update(x, eps_hat, zi, i, o.beta, o.alpha, o.alphabar)
+    assert close(out, x.numpy()), rel_max(out.cpu().numpy(), x.numpy())
+    e.close()
+
+
+def test_two_engines_keep_their_own_settings(engine_cls):
+    """Tile / path selection is per handle (it was process-global): forcing a tile or switching the narrow-net
+    kernels on one engine leaves another engine's launches - and therefore its bits - alone."""
+    L, W, T, H, B = 48, 56, 9, 1, 40
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=51), H)
+    x0 = synth.synth_latents(B, L, seed=52)
+    eps, t, masks = synth.synth_train_randoms(B, L, T, 1.0, seed=53)
+
+    def step(e):
+        e.set_params(init)
+        e.adam_reset()
+        e.train_step(x0, 1e-3, noise=eps, t=t, keep=masks)
+        return e.get_grads().cpu().numpy()
+    a = engine_cls(L, W, T, H, B)
+    base = step(a)
+    b = engine_cls(L, W, T, H, B).debug_set(tile=0, skinny=0)      # a different summation order
+    other = step(b)
+    assert not np.array_equal(base, other) and rel_l2(other, base) <= 2e-5
+    assert np.array_equal(step(a), base)                            # engine a is where it was
+    b.debug_set(tile=4)
+    assert np.array_equal(step(a), base)
+    a.close(); b.close()
 
 
 def test_philox_forward_keep(engine_cls):

@@ -159,6 +159,27 @@ def test_bench_step_mix():
     assert bench.sample_flops(5429, 340, 78, 1) == pytest.approx(4.12e9, rel=1e-2)
 
 
+def test_bench_window_rule():
+    """bench.py times several K-step windows along the cyclic walk: their number covers whole job cycles and the
+    combination is unbiased in the train:sample mix even when one window cannot hold the mix (K = 20: 3 or 4 train steps)."""
+    import bench
+    cycle, n_train = 93, 15
+    for K in (20, 93, 186, 100, 7):
+        w = bench.pick_windows(K, cycle)
+        assert 5 <= w <= 24
+        trains, k = [], cycle + 5          # pre-heat + warm-up
+        for _ in range(w):
+            trains.append(sum(bench.is_train(k + i, n_train, cycle) for i in range(K)))
+            k += K
+        t_train, t_sample = 0.6, 0.054
+        ms = [n * t_train + (K - n) * t_sample for n in trains]
+        ms[0] *= 1.5                       # one slow outlier window must not move the figure much
+        dt, kinds = bench.combine_windows(ms, trains, K)
+        exact = K * (n_train * t_train + (cycle - n_train) * t_sample) / cycle
+        assert abs(kinds["train"] / K - n_train / cycle) <= 0.012, (K, w, trains)
+        assert abs(dt * 1e3 - exact) <= 0.03 * exact, (K, w, dt * 1e3, exact)
+
+
 def test_shard_rows_partition():
     from sdrm_amd.parallel import shard_rows
     for n, w in [(8192, 8), (5429, 8), (7, 3), (3, 8)]:

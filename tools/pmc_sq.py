@@ -8,7 +8,10 @@ Per kernel and grid size: the wave-cycle fractions (parked on s_waitcnt/s_barrie
 bank-conflict cycles, and the matrix-pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), the
 kernel cycles taken from SQ_BUSY_CYCLES / 32 (the counter sums the busy cycles of the 32 shader engines' SQs...) - when
 that normalisation is in doubt, compare kernels with each other rather than against 1.0."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdrm_amd import _build  # noqa: E402  (stamp: hash of the kernel sources the counters belong to)
 
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
@@ -38,5 +41,6 @@ for key, c in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)
     print(f"{k[:96]:96s} grid {grid:8d} x{calls:4d}  mfma busy/SIMD {row['mfma_busy_per_simd_cycles']:9.0f} cyc  parked {row['frac_wave_parked']:.2f} "
           f"issue-stalled {row['frac_wave_issue_stalled']:.2f} issuing {row['frac_wave_issuing']:.2f} lds-conflict {row['lds_bank_conflict_per_wave_cycle']:.3f}")
 if len(sys.argv) > 2:
-    json.dump({"note": "mfma_busy_per_simd_cycles / (kernel duration x shader clock) = matrix-pipe utilisation", "kernels": out},
+    json.dump({"note": "mfma_busy_per_simd_cycles / (kernel duration x shader clock) = matrix-pipe utilisation",
+               "source_hash": _build.source_hash(), "git_head": os.environ.get("GIT_HEAD"), "kernels": out},
               open(sys.argv[2], "w"), indent=1)

@@ -12,7 +12,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdrm_amd import _build  # noqa: E402  (stamp: hash of the kernel sources the counters belong to)
 
 
 def per_kernel(d):
@@ -39,7 +43,8 @@ def main():
     for name, rows in res.items():
         n = sum(r["launches"] for r in rows) or 1
         summary[name] = {"hbm_bytes_per_launch_mean": int(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n), "by_grid": rows}
-    json.dump({"unit": "bytes", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950 correction]", "kernels": summary},
+    json.dump({"unit": "bytes", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024  [gfx950 correction]",
+               "source_hash": _build.source_hash(), "git_head": os.environ.get("GIT_HEAD"), "kernels": summary},
               open(dst, "w"), indent=1)
     for name, v in summary.items():
         print(f"{v['hbm_bytes_per_launch_mean'] / 1e6:10.2f} MB  {name[:110]}")
