@@ -304,6 +304,8 @@ def main():
                     help="skip the extra legs on the other BASELINE.json configs (steps/s, launches per step, roofline time)")
     ap.add_argument("--windows", type=int, default=5, help="least number of timed repeats of the --steps window")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--exchange", default="rccl-abi", choices=["rccl-abi", "torch"],
+                    help="N > 1: collectives issued inside libsdrm_hip.so over RCCL (default) or by torch.distributed between the phases")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
     args = ap.parse_args()
@@ -321,7 +323,7 @@ def main():
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
     from sdrm_amd.engine import Engine
-    from sdrm_amd.parallel import ShardedTrainer, shard_rows
+    from sdrm_amd.parallel import RcclTrainer, ShardedTrainer, shard_rows
 
     wl = WL
     L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
@@ -330,7 +332,10 @@ def main():
     eng = Engine(L, W, T, H, max_rows=max(rows, n_local))
     eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
     x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)[row0:row0 + rows]).cuda()
-    trainer = ShardedTrainer(eng, rank, world)
+    # N > 1 over RCCL: the exchange is issued by the library itself (sdrm_train_step_sharded); --exchange torch keeps the
+    # torch.distributed collectives between the three phases (the only form a gloo rehearsal can run)
+    use_abi = world > 1 and args.exchange == "rccl-abi" and args.backend == "nccl"
+    trainer = RcclTrainer(eng, rank, world) if use_abi else ShardedTrainer(eng, rank, world)
     job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
 
     def barrier():
@@ -436,7 +441,9 @@ def main():
                        "global_batch": B, "n_sample": n, "step_mix": f"{n_train} train : {T} sample per job cycle",
                        "timed_train_steps": round(kinds["train"], 3), "timed_sample_steps": round(kinds["sample"], 3),
                        "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
-                       "collectives": (f"{args.backend}: all-reduce of 5 f64 loss sums + flat f32 gradient per train step"
+                       "collectives": ((("RCCL issued by libsdrm_hip.so (sdrm_train_step_sharded)" if use_abi else
+                                         f"torch.distributed/{args.backend} between the C-ABI phases")
+                                        + ": all-reduce of 5 f64 loss sums + flat f32 gradient in two buckets per train step")
                                        if world > 1 else "none")},
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),

@@ -46,7 +46,8 @@ enum sdrm_status {
   SDRM_ERR_SHAPE = -2,  /* rows > max_rows, L/W/T/H outside the supported envelope */
   SDRM_ERR_HIP = -3,    /* a HIP runtime call failed */
   SDRM_ERR_STATE = -4,  /* call order violated (e.g. backward before forward) */
-  SDRM_ERR_NOMEM = -5
+  SDRM_ERR_NOMEM = -5,
+  SDRM_ERR_RCCL = -6    /* librccl could not be loaded, or an RCCL call failed */
 };
 
 /* Where the randomness of a call comes from (SURVEY.md §8b "two RNG modes"). */
@@ -127,6 +128,31 @@ int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream);
 /* Single-GPU convenience: (1)+(2)+(3) back to back on `stream`. */
 int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,
                     uint64_t seed, uint64_t step, float noise_divider, float* loss, void* stream);
+/* ---- multi-GPU: the user-sharded train step with its exchange inside the library ---------- *
+ * No reference counterpart (the reference is single-device, train_SDRM.py:18): rows (users) of the global batch are
+ * partitioned over one process per GPU; parameters, Adam state and schedule are replicated.  Per step two things cross
+ * GPUs, both as RCCL all-reduce(sum) issued by the library itself: the 5 float64 loss sums (var(R) and both mse means of
+ * train_SDRM.py:196-198 are over the GLOBAL batch) and the flat gradient [P], in the two buckets of sdrm_grad_buckets,
+ * the first one overlapped with the upper layers' weight gradients on an auxiliary stream.  Sampling needs no exchange.
+ *
+ * librccl is loaded at run time (dlopen "librccl.so.1", or $SDRM_RCCL_LIB); a process that already holds one - e.g. a
+ * PyTorch process - shares that instance.  Either
+ *   sdrm_comm_unique_id (rank 0; ship the 128 bytes to the other ranks by any channel) + sdrm_comm_init_rank (all ranks;
+ *   the library owns the communicator), or
+ *   sdrm_allreduce_init (adopts a ncclComm_t the caller made with the same librccl; not destroyed by the library).
+ * aux_stream: a hipStream_t for the overlapped bucket (NULL = the library creates one). */
+enum { SDRM_COMM_ID_BYTES = 128 };
+int sdrm_comm_unique_id(void* id_host);
+int sdrm_comm_init_rank(sdrm_engine* e, int nranks, int rank, const void* id_host);
+int sdrm_allreduce_init(sdrm_engine* e, void* rccl_comm, void* aux_stream);
+int sdrm_comm_info(const sdrm_engine* e, int* nranks, int* rank);   /* nranks 0 / rank -1: no communicator */
+int sdrm_comm_destroy(sdrm_engine* e);                             /* also done by sdrm_destroy */
+/* sdrm_train_forward (this rank's rows, first global row row0) -> all-reduce of the loss sums -> sdrm_train_backward_begin
+ * -> all-reduce of the first bucket beside sdrm_train_backward_finish -> all-reduce of the second bucket -> sdrm_adam_step.
+ * `loss` (device float, may be NULL) receives the GLOBAL loss.  With one rank it equals sdrm_train_step bit for bit. */
+int sdrm_train_step_sharded(sdrm_engine* e, const float* x0, int B, int64_t row0, float lr, int mode,
+                            const sdrm_train_randoms* rnd, uint64_t seed, uint64_t step, float noise_divider, float* loss,
+                            void* stream);
 /* Outputs of the last sdrm_train_forward: P,S,Q as [3,B,L] (parity tests). */
 int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream);
 

@@ -44,6 +44,9 @@ int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode);
  * Results do not depend on it (rows are independent and randoms are keyed by row). */
 int sdrm_debug_set_chains(sdrm_engine* e, int chains);
 
+/* The engine's ncclComm_t (NULL without one): lets a test hand a communicator made elsewhere to sdrm_allreduce_init. */
+void* sdrm_debug_comm_handle(const sdrm_engine* e);
+
 /* Host-side planning of one split-K weight-gradient launch with the default settings (no device work): for a reduction
  * over `rows` stacked rows into an [n_out, k_in] gradient, the number of K-slices (slabs) and the rows per slice the
  * engine would use.  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows, slices <= 64, and

@@ -41,6 +41,13 @@ SIGNATURES = {
     "sdrm_adam_step": (c_int, [c_void_p, c_void_p, c_float, c_void_p]),
     "sdrm_train_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, C.POINTER(TrainRandoms), c_uint64, c_uint64,
                                 c_float, c_void_p, c_void_p]),
+    "sdrm_comm_unique_id": (c_int, [c_void_p]),
+    "sdrm_comm_init_rank": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "sdrm_allreduce_init": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_comm_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
+    "sdrm_comm_destroy": (c_int, [c_void_p]),
+    "sdrm_train_step_sharded": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_float, c_int, C.POINTER(TrainRandoms), c_uint64,
+                                        c_uint64, c_float, c_void_p, c_void_p]),
     "sdrm_get_train_outputs": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sdrm_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_uint64, c_uint64, c_int64,
                              c_void_p, c_void_p]),
@@ -72,6 +79,7 @@ SIGNATURES = {
     "sdrm_debug_set_chains": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_fused_reverse": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_skinny": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_comm_handle": (c_void_p, [c_void_p]),
     "sdrm_debug_plan_wgrad": (c_int, [c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int)]),
     "sdrm_debug_gemm_time": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float), c_void_p]),
     "sdrm_debug_gemm": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -79,7 +87,7 @@ SIGNATURES = {
 
 RNG_EXPLICIT, RNG_PHILOX = 0, 1
 STATUS = {0: "SDRM_OK", -1: "SDRM_ERR_ARG", -2: "SDRM_ERR_SHAPE", -3: "SDRM_ERR_HIP", -4: "SDRM_ERR_STATE",
-          -5: "SDRM_ERR_NOMEM"}
+          -5: "SDRM_ERR_NOMEM", -6: "SDRM_ERR_RCCL"}
 
 
 def lib_path() -> str:

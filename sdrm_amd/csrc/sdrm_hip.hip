@@ -13,6 +13,7 @@
 #include "../../include/sdrm_hip.h"
 #include "../../include/sdrm_hip_debug.h"
 #include "elementwise.h"
+#include "exchange.h"
 #include "feed.h"
 #include "gemm.h"
 #include "rank.h"
@@ -90,6 +91,7 @@ struct sdrm_engine {
   bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
+  Exchange xch;                      // RCCL communicator of the user-sharded step (sdrm_comm_init_rank / sdrm_allreduce_init)
   mutable int64_t n_launches = 0;    // kernel launches issued through this handle since sdrm_create
   uint64_t params_version = 0;       // bumped whenever the parameters change (set_params, Adam)
   uint64_t smp_b0_version = 0;       // parameters the sampler's bias table B0tab was built from
@@ -712,6 +714,7 @@ int sdrm_destroy(sdrm_engine* e) {
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   (void)hipDeviceSynchronize();
+  (void)sdrm_comm_destroy(e);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   for (int c = 0; c < 3; ++c) {
     if (e->ev_join[c]) (void)hipEventDestroy(e->ev_join[c]);
@@ -1071,6 +1074,125 @@ int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, 
   if (!rc) rc = sdrm_train_backward(e, nullptr, nullptr, loss, stream);
   e->fold_sums = false;
   if (rc) return rc;
+  return sdrm_adam_step(e, nullptr, lr, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The exchange step of the user-sharded train step, RCCL called from inside the library.
+#define NCCL_TRY(e, api, call)                                                                  \
+  do {                                                                                          \
+    ncclResult_t _r = (call);                                                                   \
+    if (_r != ncclSuccess) {                                                                    \
+      (e)->err = std::string(#call) + ": " + (api)->GetErrorString(_r);                         \
+      return SDRM_ERR_RCCL;                                                                     \
+    }                                                                                           \
+  } while (0)
+
+int sdrm_comm_unique_id(void* id_host) {
+  if (!id_host) return SDRM_ERR_ARG;
+  const RcclApi* api = rccl_api(nullptr);
+  if (!api) return SDRM_ERR_RCCL;
+  static_assert(sizeof(ncclUniqueId) == SDRM_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return SDRM_ERR_RCCL;
+  std::memcpy(id_host, &id, sizeof(id));
+  return SDRM_OK;
+}
+
+namespace {
+int exchange_streams(sdrm_engine* e, void* aux_stream) {
+  Exchange& x = e->xch;
+  if (aux_stream) { x.aux = (hipStream_t)aux_stream; x.aux_owned = false; }
+  else { HIP_TRY(e, hipStreamCreateWithFlags(&x.aux, hipStreamNonBlocking)); x.aux_owned = true; }
+  HIP_TRY(e, hipEventCreateWithFlags(&x.ev_bucket, hipEventDisableTiming));
+  HIP_TRY(e, hipEventCreateWithFlags(&x.ev_done, hipEventDisableTiming));
+  return SDRM_OK;
+}
+}  // namespace
+
+int sdrm_comm_init_rank(sdrm_engine* e, int nranks, int rank, const void* id_host) {
+  if (!e || !id_host || nranks < 1 || rank < 0 || rank >= nranks) return fail(e, SDRM_ERR_ARG, "sdrm_comm_init_rank: bad argument");
+  if (e->xch.comm) return fail(e, SDRM_ERR_STATE, "sdrm_comm_init_rank: this engine already has a communicator");
+  std::string why;
+  const RcclApi* api = rccl_api(&why);
+  if (!api) return fail(e, SDRM_ERR_RCCL, why);
+  HIP_TRY(e, hipSetDevice(e->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id_host, sizeof(id));
+  ncclComm_t comm = nullptr;
+  NCCL_TRY(e, api, api->CommInitRank(&comm, nranks, id, rank));
+  e->xch.comm = comm; e->xch.comm_owned = true; e->xch.nranks = nranks; e->xch.rank = rank;
+  return exchange_streams(e, nullptr);
+}
+
+int sdrm_allreduce_init(sdrm_engine* e, void* rccl_comm, void* aux_stream) {
+  if (!e || !rccl_comm) return fail(e, SDRM_ERR_ARG, "sdrm_allreduce_init: null pointer");
+  if (e->xch.comm) return fail(e, SDRM_ERR_STATE, "sdrm_allreduce_init: this engine already has a communicator");
+  std::string why;
+  const RcclApi* api = rccl_api(&why);
+  if (!api) return fail(e, SDRM_ERR_RCCL, why);
+  ncclComm_t comm = (ncclComm_t)rccl_comm;
+  int n = 0, r = -1;
+  NCCL_TRY(e, api, api->CommCount(comm, &n));
+  NCCL_TRY(e, api, api->CommUserRank(comm, &r));
+  e->xch.comm = comm; e->xch.comm_owned = false; e->xch.nranks = n; e->xch.rank = r;
+  return exchange_streams(e, aux_stream);
+}
+
+int sdrm_comm_info(const sdrm_engine* e, int* nranks, int* rank) {
+  if (!e) return SDRM_ERR_ARG;
+  if (nranks) *nranks = e->xch.comm ? e->xch.nranks : 0;
+  if (rank) *rank = e->xch.comm ? e->xch.rank : -1;
+  return SDRM_OK;
+}
+
+void* sdrm_debug_comm_handle(const sdrm_engine* e) { return e ? (void*)e->xch.comm : nullptr; }
+
+int sdrm_comm_destroy(sdrm_engine* e) {
+  if (!e) return SDRM_ERR_ARG;
+  Exchange& x = e->xch;
+  if (!x.comm) return SDRM_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  if (x.comm_owned)
+    if (const RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(x.comm);
+  if (x.ev_bucket) (void)hipEventDestroy(x.ev_bucket);
+  if (x.ev_done) (void)hipEventDestroy(x.ev_done);
+  if (x.aux && x.aux_owned) (void)hipStreamDestroy(x.aux);
+  x = Exchange{};
+  return SDRM_OK;
+}
+
+// One user-sharded train step, exchange included (what a non-Python caller needs: sdrm_amd/parallel.py does the same
+// with torch.distributed between the three phases).  Order on `stream` unless noted:
+//   forwards + local loss sums -> all-reduce(5 doubles) -> loss seeds, dgrad chain, layer-0 weight gradient, first
+//   bucket final -> [aux stream: all-reduce(first bucket)] beside the upper layers' weight gradients -> second bucket
+//   final -> [aux: all-reduce(second bucket)] -> Adam.
+// Every collective of the communicator is ordered against the next by stream dependencies, on every rank alike.
+int sdrm_train_step_sharded(sdrm_engine* e, const float* x0, int B, int64_t row0, float lr, int mode,
+                            const sdrm_train_randoms* rnd, uint64_t seed, uint64_t step, float nd, float* loss, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  Exchange& x = e->xch;
+  if (!x.comm) return fail(e, SDRM_ERR_STATE, "sdrm_train_step_sharded: no communicator (sdrm_comm_init_rank / sdrm_allreduce_init)");
+  const RcclApi* api = rccl_api(nullptr);
+  if (!api) return fail(e, SDRM_ERR_RCCL, "librccl is gone");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = sdrm_train_forward(e, x0, B, row0, mode, rnd, seed, step, nd, e->sums, stream);
+  if (rc) return rc;
+  NCCL_TRY(e, api, api->AllReduce(e->sums, e->sums, 5, ncclDouble, ncclSum, x.comm, st));
+  rc = sdrm_train_backward_begin(e, e->sums, nullptr, loss, stream);
+  if (rc) return rc;
+  const int64_t n0 = e->off_a0, n1 = e->P - e->off_a0;
+  HIP_TRY(e, hipEventRecord(x.ev_bucket, st));
+  HIP_TRY(e, hipStreamWaitEvent(x.aux, x.ev_bucket, 0));
+  NCCL_TRY(e, api, api->AllReduce(e->g, e->g, (size_t)n0, ncclFloat, ncclSum, x.comm, x.aux));
+  rc = sdrm_train_backward_finish(e, nullptr, stream);
+  if (rc) return rc;
+  HIP_TRY(e, hipEventRecord(x.ev_bucket, st));
+  HIP_TRY(e, hipStreamWaitEvent(x.aux, x.ev_bucket, 0));
+  NCCL_TRY(e, api, api->AllReduce(e->g + n0, e->g + n0, (size_t)n1, ncclFloat, ncclSum, x.comm, x.aux));
+  HIP_TRY(e, hipEventRecord(x.ev_done, x.aux));
+  HIP_TRY(e, hipStreamWaitEvent(st, x.ev_done, 0));
   return sdrm_adam_step(e, nullptr, lr, stream);
 }
 

@@ -207,6 +207,46 @@ class Engine:
         self._check(rc, "sdrm_train_step")
         return self._loss
 
+    # ------------------------------------------------------------------ multi-GPU exchange inside the library
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL unique id (rank 0 calls this and ships the bytes to the other ranks by any channel)."""
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().sdrm_comm_unique_id(buf)
+        if rc != 0:
+            raise SdrmError(f"sdrm_comm_unique_id: {_lib.STATUS.get(rc, rc)} (librccl could not be loaded?)")
+        return buf.raw
+
+    def comm_init_rank(self, nranks: int, rank: int, unique_id: bytes):
+        """Joins the RCCL communicator of the user-sharded step (the library owns it)."""
+        if len(unique_id) != 128:
+            raise SdrmError("comm_init_rank: the unique id is 128 bytes")
+        self._check(self.lib.sdrm_comm_init_rank(self._h, int(nranks), int(rank), C.c_char_p(unique_id)), "sdrm_comm_init_rank")
+        return self
+
+    def comm_info(self):
+        n, r = C.c_int(), C.c_int()
+        self._check(self.lib.sdrm_comm_info(self._h, C.byref(n), C.byref(r)), "sdrm_comm_info")
+        return int(n.value), int(r.value)
+
+    def train_step_sharded(self, x0, lr, row0=0, noise=None, t=None, keep=None, seed=0, step=0, nd=1.0):
+        """One step on this rank's rows with both exchanges (loss sums, gradient buckets) issued by the library over
+        RCCL; returns the device scalar holding the GLOBAL loss."""
+        x0 = self._dev(x0, torch.float32)
+        B = x0.shape[0]
+        if x0.dim() != 2 or x0.shape[1] != self.L:
+            raise SdrmError(f"train_step_sharded: x0 must be [B,{self.L}]")
+        self._x0 = x0
+        if noise is not None:
+            rnd = self._randoms(noise, t, keep, B)
+            rc = self.lib.sdrm_train_step_sharded(self._h, _ptr(x0), B, int(row0), float(lr), _lib.RNG_EXPLICIT, C.byref(rnd),
+                                                  0, 0, float(nd), _ptr(self._loss), _stream())
+        else:
+            rc = self.lib.sdrm_train_step_sharded(self._h, _ptr(x0), B, int(row0), float(lr), _lib.RNG_PHILOX, None, int(seed),
+                                                  int(step), float(nd), _ptr(self._loss), _stream())
+        self._check(rc, "sdrm_train_step_sharded")
+        return self._loss
+
     def train_outputs(self, B):
         out = torch.empty(3, B, self.L, dtype=torch.float32, device=self.device)
         self._check(self.lib.sdrm_get_train_outputs(self._h, _ptr(out), _stream()), "sdrm_get_train_outputs")

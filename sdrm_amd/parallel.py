@@ -16,8 +16,13 @@ step, nothing else:
 Randomness is Philox keyed by the GLOBAL row index, so G ranks draw exactly what one rank draws.
 Sampling shards users with no communication at all.
 
-The trainer only needs an object with `train_forward / train_backward / adam_step` (the three phases
-of include/sdrm_hip.h); the CPU tests drive it with an oracle-backed stand-in over gloo."""
+Two drivers of the same step:
+  * `ShardedTrainer`: the three phases of include/sdrm_hip.h with `torch.distributed` collectives between them.  It only
+    needs an object with `train_forward / train_backward / adam_step`; the CPU tests drive it with an oracle-backed
+    stand-in over gloo, and with the real Engine on a shared GPU when one is present.
+  * `RcclTrainer`: `sdrm_train_step_sharded` - the collectives are issued by the library itself over RCCL (what a
+    non-Python caller uses; one C call per step, no Python between the phases).  `torch.distributed` is used once, to
+    ship the 128-byte RCCL unique id from rank 0."""
 from __future__ import annotations
 
 import torch
@@ -69,3 +74,22 @@ class ShardedTrainer:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
         e.adam_step(lr, grad=self.grad)
         return loss
+
+
+class RcclTrainer:
+    """Same `train_step` signature as ShardedTrainer; the exchange lives in libsdrm_hip.so (sdrm_train_step_sharded)."""
+
+    def __init__(self, engine, rank: int = 0, world: int = 1, unique_id: bytes | None = None, group=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        if unique_id is None:
+            box = [type(engine).comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        engine.comm_init_rank(world, rank, unique_id)
+
+    def train_step(self, x0_local, lr, row0=0, step=0, seed=0, nd=1.0, explicit=None):
+        if explicit is None:
+            return self.engine.train_step_sharded(x0_local, lr, row0=row0, seed=seed, step=step, nd=nd)
+        noise, t, keep = explicit
+        return self.engine.train_step_sharded(x0_local, lr, row0=row0, noise=noise, t=t, keep=keep, nd=nd)

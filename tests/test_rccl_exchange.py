@@ -1,0 +1,95 @@
+"""The exchange of the user-sharded train step as the library issues it: RCCL called from inside libsdrm_hip.so
+(include/sdrm_hip.h: sdrm_comm_unique_id / sdrm_comm_init_rank / sdrm_allreduce_init / sdrm_train_step_sharded).
+
+A one-GPU box can hold one RCCL rank per device, so these tests run a communicator of ONE rank: every RCCL call of the
+step is really made (unique id, communicator, three all-reduces per step on two streams, the event hand-offs), only the
+wire is trivial.  The arithmetic of N > 1 ranks is covered by tests/test_sharded_gloo.py (two processes) and
+test_hip_parity.py::test_sharded_equals_single.  Needs a real MI355X: `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from sdrm_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine_cls():
+    from sdrm_amd.engine import Engine
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return Engine
+
+
+@pytest.mark.parametrize("dims", [(340, 340, 78, 1, 1024), (40, 40, 93, 5, 107), (96, 72, 10, 0, 33)])
+def test_one_rank_rccl_step_equals_train_step(engine_cls, dims):
+    """sdrm_train_step_sharded over a 1-rank RCCL communicator == sdrm_train_step, bit for bit, over three steps
+    (loss, gradient, parameters, Adam moments): the bucketed backward, the in-place all-reduces on the internal gradient
+    and the stream hand-offs change nothing."""
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=61), H)
+    x0 = synth.synth_latents(B, L, seed=62)
+    a, b = engine_cls(L, W, T, H, B), engine_cls(L, W, T, H, B)
+    a.set_params(init); b.set_params(init)
+    assert b.comm_info() == (0, -1)
+    b.comm_init_rank(1, 0, engine_cls.comm_unique_id())
+    assert b.comm_info() == (1, 0)
+    for step in range(3):
+        lr = 1e-3 * (1 - step / 3)
+        la = float(a.train_step(x0, lr, seed=9, step=step, nd=0.9).cpu())
+        lb = float(b.train_step_sharded(x0, lr, row0=0, seed=9, step=step, nd=0.9).cpu())
+        assert la == lb, (step, la, lb)
+        assert bool((a.get_grads() == b.get_grads()).all()), step
+        assert bool((a.get_params() == b.get_params()).all()), step
+    (ma, va, ta), (mb, vb, tb) = a.get_adam_state(), b.get_adam_state()
+    assert ta == tb == 3 and bool((ma == mb).all()) and bool((va == vb).all())
+    a.close(); b.close()
+
+
+def test_adopted_communicator_and_errors(engine_cls):
+    """sdrm_allreduce_init adopts a ncclComm_t made by the caller's own RCCL code (here: made through a first engine) and
+    does not destroy it; a step without a communicator, or a second communicator on one engine, is an error."""
+    from sdrm_amd.engine import SdrmError
+    L, W, T, H, B = 48, 48, 7, 1, 20
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=63), H)
+    x0 = synth.synth_latents(B, L, seed=64)
+    e = engine_cls(L, W, T, H, B)
+    e.set_params(init)
+    with pytest.raises(SdrmError, match="no communicator"):
+        e.train_step_sharded(x0, 1e-3, seed=1, step=0)
+    e.comm_init_rank(1, 0, engine_cls.comm_unique_id())
+    with pytest.raises(SdrmError, match="already has a communicator"):
+        e.comm_init_rank(1, 0, engine_cls.comm_unique_id())
+    loss = float(e.train_step_sharded(x0, 1e-3, seed=1, step=0).cpu())
+    ref = engine_cls(L, W, T, H, B)
+    ref.set_params(init)
+    assert loss == float(ref.train_step(x0, 1e-3, seed=1, step=0).cpu())
+    # a second engine adopts the first one's communicator (as a caller with its own RCCL code would hand one in)
+    other = engine_cls(L, W, T, H, B)
+    other.set_params(init)
+    comm = e.lib.sdrm_debug_comm_handle(e._h)
+    assert comm
+    assert other.lib.sdrm_allreduce_init(other._h, C.c_void_p(comm), None) == 0 and other.comm_info() == (1, 0)
+    assert float(other.train_step_sharded(x0, 1e-3, seed=1, step=0).cpu()) == loss
+    assert bool((other.get_params() == e.get_params()).all())
+    other.close()                                    # must NOT destroy the adopted communicator ...
+    l2 = float(e.train_step_sharded(x0, 1e-3, seed=1, step=1).cpu())   # ... its owner still uses it
+    assert l2 == float(ref.train_step(x0, 1e-3, seed=1, step=1).cpu())
+    assert e.lib.sdrm_comm_destroy(e._h) == 0 and e.comm_info() == (0, -1)
+    e.close(); ref.close()
+
+
+def test_explicit_randoms_through_the_sharded_step(engine_cls):
+    L, W, T, H, B = 100, 100, 12, 2, 64
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=65), H)
+    x0 = synth.synth_latents(B, L, seed=66)
+    eps, t, keep = synth.synth_train_randoms(B, L, T, 1.0, seed=67)
+    a, b = engine_cls(L, W, T, H, B), engine_cls(L, W, T, H, B)
+    a.set_params(init); b.set_params(init)
+    b.comm_init_rank(1, 0, engine_cls.comm_unique_id())
+    la = float(a.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
+    lb = float(b.train_step_sharded(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
+    assert la == lb and bool((a.get_params() == b.get_params()).all())
+    a.close(); b.close()

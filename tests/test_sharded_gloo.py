@@ -146,6 +146,61 @@ def test_two_rank_gloo_matches_single_process(overlap):
     assert np.array_equal(results[0][1], results[1][1])       # replicas stay bit-identical
 
 
+def _gpu_worker(rank, world, port, init_flat, x0, dims, q, overlap):
+    """One rank of the real thing on a shared GPU: the product's Engine + ShardedTrainer, gloo carrying the collectives
+    (RCCL refuses two ranks on one device; the RCCL path itself is driven by tests/test_rccl_exchange.py)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdrm_amd.engine import Engine
+    gl, gw, gt, gh, gb = dims
+    torch.cuda.set_device(0)
+    eng = Engine(gl, gw, gt, gh, max_rows=gb)
+    eng.set_params(init_flat)
+    tr = ShardedTrainer(eng, rank, world, overlap=overlap)
+    r0, rows = shard_rows(gb, rank, world)
+    losses = []
+    for step in range(3):
+        loss = tr.train_step(torch.from_numpy(x0[r0:r0 + rows]).cuda(), LR * (1 - step / 3), row0=r0, step=step, seed=SEED, nd=ND)
+        losses.append(float(loss.cpu()))
+    q.put((rank, eng.get_params().cpu().numpy(), losses))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_rank_gloo_real_engine_on_shared_gpu(overlap):
+    """The same two-rank run with the REAL engine in each process (both on cuda:0): the user-sharded step - ragged split,
+    Philox keyed by the global row, loss sums and gradient buckets exchanged between the C-ABI phases - reproduces the
+    single-engine sdrm_train_step trajectory, and the replicas stay bit-identical."""
+    from sdrm_amd.engine import Engine
+    dims = (72, 80, 9, 2, 45)
+    gl, gw, gt, gh, gb = dims
+    init_flat = synth.flatten_params(synth.init_params(gl, gw, gt, gh, seed=13), gh)
+    x0 = synth.synth_latents(gb, gl, seed=14)
+    single = Engine(gl, gw, gt, gh, max_rows=gb)
+    single.set_params(init_flat)
+    ref_losses = [float(single.train_step(x0, LR * (1 - s / 3), seed=SEED, step=s, nd=ND).cpu()) for s in range(3)]
+    ref = single.get_params().cpu().numpy()
+    single.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, init_flat, x0, dims, q, overlap)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, flat, losses in results:
+        assert np.sqrt(((flat - ref) ** 2).sum() / (ref ** 2).sum()) < 1e-5, rank
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    assert np.array_equal(results[0][1], results[1][1])
+
+
 def test_oracle_phases_equal_oracle_step():
     """The three-phase decomposition (sums -> seeds) is the same arithmetic as Oracle.train_step."""
     init = synth.init_params(L, W, T, H, seed=13)
