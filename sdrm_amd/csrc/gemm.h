@@ -103,7 +103,7 @@ struct GemmArgs {
   const float* aux; int ldaux; const float* slopeE; float* slope_partial;
   // EPI_SLAB
   size_t slab_stride; float* dbias; int dbias_stride;
-  unsigned long long* stamps;   // diagnostic builds only (-DSDRM_STAMPS): 4 s_memtime stamps per block
+  unsigned long long* stamps;   // diagnostic builds only (-DSDRM_STAMPS): 8 slots per block: 4 s_memtime stamps, 2 s_memrealtime
   // EPI_BIAS_TANH_G: extent of the unpadded caller buffer
   int rows_valid, cols_valid;
   // EPI_TANH_REV: sampler state X [rows][ldx] (updated in place), next step's dropped-out input U [rows][ldx];
@@ -250,6 +250,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
 #ifdef SDRM_STAMPS
   unsigned long long t_in = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+  const unsigned long long r_in = __builtin_amdgcn_s_memrealtime();   // 100 MHz: with t_in / t_out gives the clock the chip held
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -647,8 +648,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
 #ifdef SDRM_STAMPS
   if (EPI == EPI_PLAIN && p.stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
-    unsigned long long* o = p.stamps + 4 * (size_t)bid;
+    unsigned long long* o = p.stamps + 8 * (size_t)bid;
     o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
+    o[4] = r_in; o[5] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
   if (EPI == EPI_DPRELU) {
