@@ -456,7 +456,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       }
       __syncthreads();
 #ifdef SDRM_STAMPS
-      if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
+      if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_pro = __builtin_amdgcn_s_memtime();
 #endif
       if (wave_active) rd_all(fa0, fb0, 0);
       __syncthreads();   // stage 0 is overwritten from the first K-step on: every wave must hold its step-0 fragments
@@ -535,7 +535,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       ld(ra1, rb1, 3);
       __syncthreads();
 #ifdef SDRM_STAMPS
-      if (EPI == EPI_PLAIN) t_pro = __builtin_amdgcn_s_memtime();
+      if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_pro = __builtin_amdgcn_s_memtime();
 #endif
       if (wave_active) {
         const float* As = smem;
@@ -563,7 +563,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     }
   }
 #ifdef SDRM_STAMPS
-  if (EPI == EPI_PLAIN) t_loop = __builtin_amdgcn_s_memtime();
+  if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_loop = __builtin_amdgcn_s_memtime();
 #endif
 
   // ------------------------------------------------------------------ epilogue
@@ -646,11 +646,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   }
 
 #ifdef SDRM_STAMPS
-  if (EPI == EPI_PLAIN && p.stamps && tid == 0) {
+  if ((EPI == EPI_PLAIN || EPI == EPI_SLAB) && p.stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long* o = p.stamps + 8 * (size_t)bid;
     o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
     o[4] = r_in; o[5] = __builtin_amdgcn_s_memrealtime();
+    // where the work-group ran: HW_REG_HW_ID (id 4: cu_id bits 11:8, sh_id 12, se_id 15:13) and HW_REG_XCC_ID (id 20)
+    o[6] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+    o[7] = (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
   }
 #endif
   if (EPI == EPI_DPRELU) {

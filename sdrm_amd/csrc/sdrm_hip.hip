@@ -49,6 +49,7 @@ struct Tuning {
                                  // 6144 stacked rows (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile,
                                  // 12288 a tie; the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
   int wgrad_blocks = 1024;       // SDRM_WGRAD_BLOCKS: work-groups a wgrad launch aims for
+  int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
 };
 
 struct sdrm_engine {
@@ -292,6 +293,11 @@ struct WgradSpec {
   const float* dC; int lddc, Nout; const float* Act; int ldact, Kin; const float* slopeB; int S, kchunk; float* slab; float* dbias;
 };
 
+#ifdef SDRM_STAMPS
+unsigned long long* g_wgrad_stamps = nullptr;   // diagnostic build: 8 stamp slots per work-group of the batched wgrad launch
+int g_wgrad_stamps_cap = 0, g_wgrad_stamps_n = 0;
+#endif
+
 hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mrows, hipStream_t st, Prof pr) {
   GemmBatch b{};
   b.n = n;
@@ -308,9 +314,16 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     const int tiles_m = (w[k].Nout + Cfg0::BM - 1) / Cfg0::BM, tiles_n = (w[k].Kin + Cfg0::BN - 1) / Cfg0::BN;
     a.tiles_n = tiles_n; a.nblocks = tiles_m * tiles_n; a.nsplits = w[k].S;
     b.start[k] = grid;
+#ifdef SDRM_STAMPS
+    a.stamps = g_wgrad_stamps ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;
+#endif
     grid += a.nblocks * ((w[k].S + 7) / 8) * 8;   // a multiple of 8: the XCD of a work-group is the same inside its problem
   }
   b.start[n] = grid;
+#ifdef SDRM_STAMPS
+  if (grid > g_wgrad_stamps_cap) for (int k = 0; k < n; ++k) b.p[k].stamps = nullptr;
+  else g_wgrad_stamps_n = grid;
+#endif
   const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
   size_t slot = 0;
   if (rec) {
@@ -350,6 +363,7 @@ void pick_splits(const Tuning& tn, int Mrows, int Nout, int Kin, int& S, int& kc
       if (((Mrows + kc - 1) / kc) % 8 == 0) { S = c; break; }
     }
   }
+  if (tn.wgrad_slices > 0) S = std::min(tn.wgrad_slices, max_by_rows);
   kchunk = round_up((Mrows + S - 1) / S, BK);
   S = (Mrows + kchunk - 1) / kchunk;
 }
@@ -638,6 +652,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) e->tune.wgrad_blocks = std::max(1, std::atoi(env));
+  if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
   e->MPmax = round_up(3 * max_rows, 128);
@@ -1673,6 +1688,20 @@ int sdrm_debug_gemm(int variant, int cfg, const float* A, const float* B, float*
 /* Timing variant of the hook for tools/gemm_tune.py: same kernel, `reps` launches on pre-padded scratch,
  * returns the mean microseconds per launch measured with HIP events on `stream`. */
 #ifdef SDRM_STAMPS
+// diagnostic build: stamps of the engine's own batched weight-gradient launch (the last one run)
+extern "C" int sdrm_debug_wgrad_stamps_begin(int max_blocks) {
+  if (g_wgrad_stamps) (void)hipFree(g_wgrad_stamps);
+  g_wgrad_stamps = nullptr;
+  if (dalloc(&g_wgrad_stamps, (size_t)8 * max_blocks) != hipSuccess) return SDRM_ERR_NOMEM;
+  g_wgrad_stamps_cap = max_blocks; g_wgrad_stamps_n = 0;
+  return SDRM_OK;
+}
+extern "C" int sdrm_debug_wgrad_stamps_read(unsigned long long* host_out, int max_blocks) {
+  if (!g_wgrad_stamps || hipDeviceSynchronize() != hipSuccess) return SDRM_ERR_STATE;
+  const int nb = g_wgrad_stamps_n < max_blocks ? g_wgrad_stamps_n : max_blocks;
+  if (hipMemcpy(host_out, g_wgrad_stamps, (size_t)nb * 64, hipMemcpyDeviceToHost) != hipSuccess) return SDRM_ERR_HIP;
+  return nb;
+}
 // host_out: 8 slots per block (gemm.h); `warm` launches first, back to back, so that the clock the stamps see is the one
 // the chip holds under this load (MI355X_MICROARCH.md, DVFS give-back item 6: >= 2 s)
 extern "C" int sdrm_debug_gemm_stamps(int variant, int cfg, int M, int N, int K, unsigned long long* host_out, int max_blocks,
