@@ -235,6 +235,27 @@ int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t*
  * aligned, may be null) receives x >= threshold.  Inputs must not contain NaN. */
 int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream);
 
+/* The VAE decode hook on the device (reference: train_SDRM.py:212-214 `decoder = Linear(latent, hidden) -> Tanh ->
+ * Linear(hidden, N_ITEMS)`, :252-254 `VAE.decode`, called by sample_ddpm at :49 / :61 on the sampled latents): two launches of
+ * the engine's fp32 MFMA GEMM with the bias + tanh / bias epilogues.  The struct holds DEVICE pointers to the four nn.Linear
+ * tensors as PyTorch stores them (weight [out, in] row-major).  z [n, latent] float32 -> out [n, n_items] float32.  Scratch
+ * (padded copies of z and of the weights, the hidden activations) is library-owned and grows on demand - this is a
+ * once-per-sampling call, not a step call. */
+typedef struct sdrm_vae_decoder {
+  const float* w1; const float* b1;   /* decoder[0]: [hidden, latent], [hidden] */
+  const float* w2; const float* b2;   /* decoder[2]: [n_items, hidden], [n_items] */
+  int latent, hidden, n_items;
+} sdrm_vae_decoder;
+int sdrm_vae_decode(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, float* out, void* stream);
+/* Decode and equal-sparsity binarisation in one call (main.py:170-180: `sample_ddpm(...)` then `np.quantile(M.flatten(),
+ * SPARSITY)` and `M >= threshold`): the first of the three radix-select sweeps over the [n, n_items] matrix is taken by the
+ * output layer's epilogue while it writes the matrix, so the matrix is written once and swept three times instead of four.
+ * raw_out [n, n_items] float32 (16-byte aligned) receives the decoded scores, or NULL to keep them in library scratch; out
+ * (uint8 [n, n_items], 4-byte aligned, may be NULL) and threshold (device float, may be NULL) are as in sdrm_equal_sparsity,
+ * and identical to what sdrm_equal_sparsity returns for the same matrix. */
+int sdrm_vae_decode_equal_sparsity(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, double q, float* raw_out,
+                                   uint8_t* out, float* threshold, void* stream);
+
 /* Recall@k and NDCG@k of a score matrix against held-out interactions (reference: utilities.py:116-171,
  * mask_training_examples + recall_at_k_batch + NDCG_binary_at_k_batch, as svd_benchmark.py:58-66 chains them).
  * scores [U, I] float32 row-major; held_* / train_* are CSR index arrays over the same U rows (int64 indptr [U+1],

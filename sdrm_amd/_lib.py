@@ -18,6 +18,11 @@ class TrainRandoms(C.Structure):
     _fields_ = [("noise", c_void_p), ("t", c_void_p), ("keep", c_void_p)]
 
 
+class VaeDecoder(C.Structure):
+    _fields_ = [("w1", c_void_p), ("b1", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("latent", c_int), ("hidden", c_int),
+                ("n_items", c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/sdrm_hip.h one to one
 SIGNATURES = {
     "sdrm_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_void_p)]),
@@ -69,6 +74,9 @@ SIGNATURES = {
     "sdrm_launch_count": (c_int64, [c_void_p]),
     "sdrm_build_info": (C.c_char_p, []),
     "sdrm_csr_rows_to_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sdrm_vae_decode": (c_int, [c_void_p, C.POINTER(VaeDecoder), c_void_p, c_int, c_void_p, c_void_p]),
+    "sdrm_vae_decode_equal_sparsity": (c_int, [c_void_p, C.POINTER(VaeDecoder), c_void_p, c_int, C.c_double, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),
     "sdrm_rank_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -33,6 +33,7 @@
 #include <type_traits>
 
 #include "philox.h"
+#include "select.h"
 
 namespace sdrm {
 
@@ -47,8 +48,11 @@ enum : int {
   EPI_DPRELU = 3,        // C = acc * prelu'(aux) ; partial sum of acc*min(aux,0) (slope gradient)
   EPI_SLAB = 4,          // C = acc into split-K slab blockIdx.z ; optional column sums (bias grad)
   EPI_PLAIN = 5,         // C = acc (debug)
-  EPI_TANH_REV = 6       // eps_hat = tanh(acc + bias) feeds the DDPM reverse update of the sampler state in place
+  EPI_TANH_REV = 6,      // eps_hat = tanh(acc + bias) feeds the DDPM reverse update of the sampler state in place
                          // (k_reverse_update fused: on-device Philox, full-resolution sampling)
+  EPI_BIAS_G = 7,        // C = acc + bias[n], bounds-checked into an unpadded caller buffer (VAE decode output layer)
+  EPI_BIAS_G_HIST = 8    // same, and the first radix-select histogram of the values written (sdrm_vae_decode_equal_sparsity:
+                         // the equal-sparsity threshold's first sweep over the [users, items] matrix rides on its producer)
 };
 
 constexpr int NTHREADS = 256;
@@ -111,6 +115,8 @@ struct GemmArgs {
   float* revX; float* revU; int rev_ldx, rev_s0, rev_n, rev_L, rev_step;
   float rev_c1, rev_sqrt_alpha, rev_sqrt_beta, rev_nd;
   uint32_t rev_seed_lo, rev_seed_hi, rev_call_id; int64_t rev_row0;
+  // EPI_BIAS_G_HIST: SelectState::hist[0][0] (2048 bins of the top 11 key bits), integer atomics
+  uint32_t* hist;
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -574,6 +580,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   float slope_sum = 0.f;
   const float slopeE = (EPI == EPI_DPRELU) ? *p.slopeE : 0.f;
   float* __restrict__ Cp = p.C;
+  // EPI_BIAS_G_HIST: the main loop is over (its last K-step ended in a barrier), so the operand stages become two copies
+  // of the 2048-bin digit histogram (lane parity picks the copy: halves the same-address serialisation on the hot bins)
+  uint32_t* hs = reinterpret_cast<uint32_t*>(smem);
+  if (EPI == EPI_BIAS_G_HIST) {
+    static_assert(EPI != EPI_BIAS_G_HIST || 2 * Cfg::STAGE >= 2 * SEL_BINS, "LDS too small for the histogram copies");
+    for (int j = tid; j < 2 * SEL_BINS; j += NTHREADS) hs[j] = 0u;
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -584,7 +598,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       const int col = tn0 + l31;
       const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G || EPI == EPI_TANH_REV) bias = p.bias[col];
+      if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G || EPI == EPI_TANH_REV || EPI == EPI_BIAS_G ||
+          EPI == EPI_BIAS_G_HIST)
+        bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -621,6 +637,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
           const int row = rbase + rowoff(r);
           if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanh_fast(acc[a][b][r] + bias);
         }
+      } else if (EPI == EPI_BIAS_G || EPI == EPI_BIAS_G_HIST) {
+        uint32_t* mine = hs + (lane & 1) * SEL_BINS;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
+          if (row < p.rows_valid && col < p.cols_valid) {
+            const float v = acc[a][b][r] + bias;
+            Cp[(size_t)row * p.ldc + col] = v;
+            if (EPI == EPI_BIAS_G_HIST) atomicAdd(&mine[float_key(v) >> sel_shift(0)], 1u);
+          }
+        }
       } else if (EPI == EPI_DPRELU) {
         const float* __restrict__ auxp = p.aux;
         float pre[NR];
@@ -656,6 +683,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     o[7] = (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
   }
 #endif
+  if (EPI == EPI_BIAS_G_HIST) {
+    __syncthreads();
+    for (int j = tid; j < SEL_BINS; j += NTHREADS) {
+      const uint32_t c = hs[j] + hs[SEL_BINS + j];
+      if (c) atomicAdd(&p.hist[j], c);
+    }
+  }
   if (EPI == EPI_DPRELU) {
     // block-wide sum of the slope-gradient partial -> one float per block (deterministic order)
 #pragma unroll

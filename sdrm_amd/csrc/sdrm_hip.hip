@@ -12,6 +12,7 @@
 
 #include "../../include/sdrm_hip.h"
 #include "../../include/sdrm_hip_debug.h"
+#include "decode.h"
 #include "elementwise.h"
 #include "exchange.h"
 #include "feed.h"
@@ -92,6 +93,9 @@ struct sdrm_engine {
   bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
+  // grow-only scratch of sdrm_vae_decode (padded latents / weights / hidden activations; the raw matrix when the caller keeps none)
+  float* dec_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t dec_cap[7] = {0, 0, 0, 0, 0, 0, 0};
   Exchange xch;                      // RCCL communicator of the user-sharded step (sdrm_comm_init_rank / sdrm_allreduce_init)
   mutable int64_t n_launches = 0;    // kernel launches issued through this handle since sdrm_create
   uint64_t params_version = 0;       // bumped whenever the parameters change (set_params, Adam)
@@ -730,6 +734,8 @@ int sdrm_destroy(sdrm_engine* e) {
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   (void)hipDeviceSynchronize();
   (void)sdrm_comm_destroy(e);
+  for (float* b : e->dec_buf)
+    if (b) (void)hipFree(b);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   for (int c = 0; c < 3; ++c) {
     if (e->ev_join[c]) (void)hipEventDestroy(e->ev_join[c]);
@@ -1533,21 +1539,15 @@ int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t*
 
 // ---------------------------------------------------------------------------------------------
 // Equal-sparsity binarisation of sampled data (main.py:177-180), csrc/select.h.
-int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream) {
-  if (!e || !x) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: null pointer");
-  if (n < 1) return fail(e, SDRM_ERR_SHAPE, "sdrm_equal_sparsity: n < 1");
-  if (!(q >= 0.0 && q <= 1.0)) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: q outside [0,1]");
-  if (((uintptr_t)x & 15u) || (out && ((uintptr_t)out & 3u)))
-    return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: x must be 16-byte and out 4-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  // np.quantile(a, q) for float32 `a` and a Python-float q (numpy 2.x: q and the virtual index take a's dtype):
-  //   virtual = float32(n-1) * float32(q); previous = floor(virtual); next = previous + 1; gamma = virtual - previous
-  // (volatile: every operation rounds to float32, no contraction)
+namespace {
+
+// np.quantile(a, q) for float32 `a` and a Python-float q (numpy 2.x: q and the virtual index take a's dtype):
+//   virtual = float32(n-1) * float32(q); previous = floor(virtual); next = previous + 1; gamma = virtual - previous
+// (volatile: every operation rounds to float32, no contraction)
+void quantile_ranks(int64_t n, double q, int64_t& r0, int64_t& r1, float& gamma) {
   volatile float q32 = (float)q;
   volatile float nm1 = (float)(n - 1);
   volatile float virt = nm1 * q32;
-  int64_t r0, r1;
-  float gamma;
   if (virt >= nm1) { r0 = r1 = n - 1; gamma = 0.f; }
   else if (virt < 0.f) { r0 = r1 = 0; gamma = 0.f; }
   else {
@@ -1558,13 +1558,19 @@ int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uin
     if (r0 > n - 1) r0 = n - 1;
     if (r1 > n - 1) r1 = n - 1;
   }
-  SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
-  HIP_TRY(e, hipGetLastError());
+}
+
+// The select sweeps from `first_pass` on (0: all three; 1: the first histogram was accumulated by the producer of x - the
+// decode GEMM's epilogue - after a k_select_init for the same ranks), then the threshold and the binarise sweep.
+int select_and_binarize(sdrm_engine* e, const float* x, int64_t n, float gamma, int first_pass, uint8_t* out, float* threshold,
+                        hipStream_t st) {
   const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
   for (int pass = 0; pass < SEL_PASSES; ++pass) {
-    if (pass == 0) SDRM_LAUNCH(e, (k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
-    else SDRM_LAUNCH(e, (k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
-    HIP_TRY(e, hipGetLastError());
+    if (pass >= first_pass) {
+      if (pass == 0) SDRM_LAUNCH(e, (k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+      else SDRM_LAUNCH(e, (k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+      HIP_TRY(e, hipGetLastError());
+    }
     SDRM_LAUNCH(e, k_select_pick, dim3(1), dim3(256), 0, st, e->sel, pass, gamma);
     HIP_TRY(e, hipGetLastError());
   }
@@ -1574,6 +1580,109 @@ int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uin
     HIP_TRY(e, hipGetLastError());
   }
   return SDRM_OK;
+}
+
+int dec_grow(sdrm_engine* e, int slot, size_t n) {
+  if (n <= e->dec_cap[slot]) return SDRM_OK;
+  if (e->dec_buf[slot]) { HIP_TRY(e, hipDeviceSynchronize()); HIP_TRY(e, hipFree(e->dec_buf[slot])); e->dec_buf[slot] = nullptr; e->dec_cap[slot] = 0; }
+  HIP_TRY(e, dalloc(&e->dec_buf[slot], n));
+  e->dec_cap[slot] = n;
+  return SDRM_OK;
+}
+
+// decoder(z) = Linear(hidden, items)(tanh(Linear(latent, hidden)(z)))   (train_SDRM.py:212-214, :252-254); with_hist: the
+// output layer's epilogue also accumulates the first select histogram of the values it writes into e->sel
+int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, int n, float* out, bool with_hist, hipStream_t st) {
+  const int Lp = round_up(d->latent, 32), Hp = round_up(d->hidden, 32), Ip = round_up(d->n_items, 32);
+  const int MP = round_up(n, 128), Hr = round_up(Hp, 128), Ir = round_up(Ip, 128);
+  enum { Z = 0, W1, B1, HID, W2, B2 };
+  int rc;
+  if ((rc = dec_grow(e, Z, (size_t)MP * Lp)) || (rc = dec_grow(e, W1, (size_t)Hr * Lp)) || (rc = dec_grow(e, B1, Hr)) ||
+      (rc = dec_grow(e, HID, (size_t)MP * Hp)) || (rc = dec_grow(e, W2, (size_t)Ir * Hp)) || (rc = dec_grow(e, B2, Ir)))
+    return rc;
+  auto pad = [&](const float* src, int rows, int cols, float* dst, int rowsP, int colsP) {
+    const int64_t total = (int64_t)rowsP * (colsP / 4);
+    SDRM_LAUNCH(e, k_pad2d, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, st, src, rows, cols, dst, rowsP, colsP);
+    return hipGetLastError();
+  };
+  HIP_TRY(e, pad(z, n, d->latent, e->dec_buf[Z], MP, Lp));
+  HIP_TRY(e, pad(d->w1, d->hidden, d->latent, e->dec_buf[W1], Hr, Lp));
+  HIP_TRY(e, pad(d->b1, 1, d->hidden, e->dec_buf[B1], 1, Hr));
+  HIP_TRY(e, pad(d->w2, d->n_items, d->hidden, e->dec_buf[W2], Ir, Hp));
+  HIP_TRY(e, pad(d->b2, 1, d->n_items, e->dec_buf[B2], 1, Ir));
+  const int rows64 = round_up(n, BM);
+  const int cfg = choose_cfg(e->tune, rows64, e->tune.nt32_max_rows);
+  {
+    GemmArgs a{};
+    a.C = e->dec_buf[HID]; a.ldc = Hp; a.bias = e->dec_buf[B1];
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, e->dec_buf[Z], Lp, e->dec_buf[W1], Lp, rows64, Hp, Lp, st,
+                                                     Prof{e, PC_FWD_L0, 2.0 * n * (double)d->hidden * d->latent}, cfg)));
+  }
+  GemmArgs a{};
+  a.C = out; a.ldc = d->n_items; a.bias = e->dec_buf[B2];
+  a.rows_valid = n; a.cols_valid = d->n_items;
+  a.hist = &e->sel->hist[0][0][0];
+  const Prof pr{e, PC_FWD_OUT, 2.0 * n * (double)d->n_items * d->hidden};
+  if (with_hist)
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_G_HIST>(a, e->dec_buf[HID], Hp, e->dec_buf[W2], Hp, rows64, Ip, Hp, st, pr, cfg)));
+  else
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_G>(a, e->dec_buf[HID], Hp, e->dec_buf[W2], Hp, rows64, Ip, Hp, st, pr, cfg)));
+  return SDRM_OK;
+}
+
+int check_decoder(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, int n, const char* who) {
+  if (!e || !d || !z || !d->w1 || !d->b1 || !d->w2 || !d->b2) return fail(e, SDRM_ERR_ARG, std::string(who) + ": null pointer");
+  if (n < 1 || n > (1 << 22) || d->latent < 1 || d->latent > 4096 || d->hidden < 1 || d->hidden > 16384 || d->n_items < 1 ||
+      d->n_items > (1 << 20))
+    return fail(e, SDRM_ERR_SHAPE, std::string(who) + ": n, latent, hidden or n_items outside the supported envelope");
+  return SDRM_OK;
+}
+
+}  // namespace
+
+int sdrm_vae_decode(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, float* out, void* stream) {
+  if (int rc = check_decoder(e, dec, z, n, "sdrm_vae_decode")) return rc;
+  if (!out) return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode: null output");
+  if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
+  return decode_launches(e, dec, z, n, out, false, (hipStream_t)stream);
+}
+
+int sdrm_vae_decode_equal_sparsity(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, double q, float* raw_out,
+                                   uint8_t* out, float* threshold, void* stream) {
+  if (int rc = check_decoder(e, dec, z, n, "sdrm_vae_decode_equal_sparsity")) return rc;
+  if (!(q >= 0.0 && q <= 1.0)) return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode_equal_sparsity: q outside [0,1]");
+  if ((raw_out && ((uintptr_t)raw_out & 15u)) || (out && ((uintptr_t)out & 3u)))
+    return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode_equal_sparsity: raw_out must be 16-byte and out 4-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (int jr = join_chains(e, st)) return jr;
+  const int64_t total = (int64_t)n * dec->n_items;
+  float* raw = raw_out;
+  if (!raw) {   // the caller wants only the 0/1 matrix: the raw scores live in the library's scratch
+    if (int rc = dec_grow(e, 6, (size_t)total)) return rc;
+    raw = e->dec_buf[6];
+  }
+  int64_t r0, r1;
+  float gamma;
+  quantile_ranks(total, q, r0, r1, gamma);
+  SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
+  HIP_TRY(e, hipGetLastError());
+  if (int rc = decode_launches(e, dec, z, n, raw, true, st)) return rc;
+  return select_and_binarize(e, raw, total, gamma, 1, out, threshold, st);
+}
+
+int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream) {
+  if (!e || !x) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: null pointer");
+  if (n < 1) return fail(e, SDRM_ERR_SHAPE, "sdrm_equal_sparsity: n < 1");
+  if (!(q >= 0.0 && q <= 1.0)) return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: q outside [0,1]");
+  if (((uintptr_t)x & 15u) || (out && ((uintptr_t)out & 3u)))
+    return fail(e, SDRM_ERR_ARG, "sdrm_equal_sparsity: x must be 16-byte and out 4-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t r0, r1;
+  float gamma;
+  quantile_ranks(n, q, r0, r1, gamma);
+  SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
+  HIP_TRY(e, hipGetLastError());
+  return select_and_binarize(e, x, n, gamma, 0, out, threshold, st);
 }
 
 // ---------------------------------------------------------------------------------------------

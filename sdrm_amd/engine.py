@@ -349,6 +349,40 @@ class Engine:
                                                  _stream()), "sdrm_equal_sparsity")
         return (out, thr) if return_threshold else out
 
+    # ------------------------------------------------------------------ VAE decode on the engine
+    def _decoder(self, w1, b1, w2, b2):
+        w1, b1, w2, b2 = (self._dev(t.detach() if isinstance(t, torch.Tensor) else t, torch.float32) for t in (w1, b1, w2, b2))
+        hidden, latent = w1.shape
+        n_items = w2.shape[0]
+        if tuple(b1.shape) != (hidden,) or tuple(w2.shape) != (n_items, hidden) or tuple(b2.shape) != (n_items,):
+            raise SdrmError("vae_decode: expected decoder[0].weight [hidden, latent], .bias [hidden], decoder[2].weight [items, hidden], .bias [items]")
+        self._keepalive = (w1, b1, w2, b2)
+        return _lib.VaeDecoder(w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), latent, hidden, n_items), latent, n_items
+
+    def vae_decode(self, z, w1, b1, w2, b2):
+        """`VAE.decode(z)` (train_SDRM.py:252-254) for decoder = Linear -> Tanh -> Linear given as its four tensors."""
+        dec, latent, n_items = self._decoder(w1, b1, w2, b2)
+        z = self._dev(z, torch.float32)
+        if z.dim() != 2 or z.shape[1] != latent:
+            raise SdrmError(f"vae_decode: z must be [n,{latent}]")
+        out = torch.empty(z.shape[0], n_items, dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_vae_decode(self._h, C.byref(dec), _ptr(z), z.shape[0], _ptr(out), _stream()), "sdrm_vae_decode")
+        return out
+
+    def vae_decode_equal_sparsity(self, z, w1, b1, w2, b2, sparsity, keep_raw=True):
+        """Decode + main.py:177-180 in one call: (binary uint8 [n, items], threshold 0-d tensor, raw scores or None)."""
+        dec, latent, n_items = self._decoder(w1, b1, w2, b2)
+        z = self._dev(z, torch.float32)
+        if z.dim() != 2 or z.shape[1] != latent:
+            raise SdrmError(f"vae_decode_equal_sparsity: z must be [n,{latent}]")
+        n = z.shape[0]
+        raw = torch.empty(n, n_items, dtype=torch.float32, device=self.device) if keep_raw else None
+        out = torch.empty(n, n_items, dtype=torch.uint8, device=self.device)
+        thr = torch.empty((), dtype=torch.float32, device=self.device)
+        self._check(self.lib.sdrm_vae_decode_equal_sparsity(self._h, C.byref(dec), _ptr(z), n, float(sparsity), _ptr(raw), _ptr(out),
+                                                            _ptr(thr), _stream()), "sdrm_vae_decode_equal_sparsity")
+        return out, thr, raw
+
     def csr_to_device(self, m):
         """(indptr i64, indices i32, data f32 | None for an all-ones matrix, shape) of a scipy sparse matrix, on the device."""
         m = m.tocsr().copy()

@@ -136,6 +136,19 @@ def synth_interactions(n_users: int, n_items: int, seed: int = 0, p_train: float
     return csr_matrix(train.astype(np.float64)), csr_matrix(held.astype(np.float64))
 
 
+def synth_vae_decoder(latent: int, hidden: int, n_items: int, seed: int = 0):
+    """Tensors of a `Linear(latent, hidden) -> Tanh -> Linear(hidden, n_items)` decoder (train_SDRM.py:212-214), drawn like
+    the reference initialises them (:224-228: xavier-uniform weights, N(0, 0.001) biases) but from numpy's RandomState:
+    (w1 [hidden, latent], b1 [hidden], w2 [n_items, hidden], b2 [n_items]), float32."""
+    rs = np.random.RandomState(seed)
+    a1, a2 = np.sqrt(6.0 / (latent + hidden)), np.sqrt(6.0 / (hidden + n_items))
+    w1 = rs.uniform(-a1, a1, size=(hidden, latent)).astype(np.float32)
+    b1 = (rs.standard_normal(hidden) * 0.001).astype(np.float32)
+    w2 = rs.uniform(-a2, a2, size=(n_items, hidden)).astype(np.float32)
+    b2 = (rs.standard_normal(n_items) * 0.001).astype(np.float32)
+    return w1, b1, w2, b2
+
+
 def synth_train_randoms(B: int, L: int, T: int, nd: float, seed: int):
     """One train step's explicit randoms: eps=nd*N(0,1) [B,L], t~U{1..T} [B] i64,
     three Bernoulli(0.5) keep-masks [3,B,L] u8 (pass order P,S,Q)."""

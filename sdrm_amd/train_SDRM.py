@@ -10,8 +10,9 @@ hyperparameter_search.py:147,386,691 can be pointed here:
     train_variational_autoencoder (:115-188)  checkpoint (:75)  resume (:66)  DEVICE (:18)
 
 What runs where: the eps-net forward/backward/Adam and the whole reverse-sampling loop run in the HIP
-engine (no torch ops); the VAE (encode/decode hooks, its pre-training) stays in PyTorch on the same
-device, exactly as the north-star asks.  The engine draws its randomness with on-device Philox keyed
+engine (no torch ops); the VAE's pre-training and its encode hook stay in PyTorch on the same device, as
+the north-star asks; the decode hook at the end of `sample_ddpm` runs on the engine's GEMM when the
+decoder is the reference's two-layer MLP and as the PyTorch module otherwise.  The engine draws its randomness with on-device Philox keyed
 by `torch.initial_seed()`-derived seeds; explicit randoms can be injected for parity runs.
 
 Differences a caller can observe (all documented in DESIGN.md): the latents of the frozen eval-mode VAE
@@ -373,6 +374,29 @@ def train_SDRM(dl, N_ITEMS, VAE_HIDDEN, VAE_LATENT, VAE_BATCH_SIZE, VAE_LR, DIFF
     return DIFF, variational_ae
 
 
+def decoder_tensors(vae_net):
+    """The four tensors of a `Linear -> Tanh -> Linear` decoder (the reference's, :212-214) if `vae_net` has one on a ROCm
+    device in float32, else None (any other decode hook is called as the module it is)."""
+    dec = getattr(vae_net, "decoder", None)
+    if not (isinstance(dec, nn.Sequential) and len(dec) == 3 and isinstance(dec[0], nn.Linear) and isinstance(dec[1], nn.Tanh)
+            and isinstance(dec[2], nn.Linear) and dec[0].bias is not None and dec[2].bias is not None):
+        return None
+    ts = (dec[0].weight, dec[0].bias, dec[2].weight, dec[2].bias)
+    if any(t.dtype != torch.float32 or not t.is_cuda for t in ts):
+        return None
+    return ts
+
+
+def _decode(eng, vae_net, latents):
+    """vae_net.decode(latents) (:49 / :61).  The reference's own decoder (this module's `VAE`, or any module that sets
+    `sdrm_engine_decode = True` and keeps the `Linear -> Tanh -> Linear` decoder) runs on the engine's MFMA GEMM
+    (`sdrm_vae_decode`); any other decode hook is called as the module it is."""
+    ts = decoder_tensors(vae_net) if (isinstance(vae_net, VAE) or getattr(vae_net, "sdrm_engine_decode", False)) else None
+    if ts is None:
+        return vae_net.decode(latents)
+    return eng.vae_decode(latents, *ts)
+
+
 @torch.no_grad()
 def sample_ddpm(n_sample, diff_net, vae_net, diff_latent_dim, noise_divider=1.0, timesteps: str = None,
                 n_timesteps=None, verbose=False):
@@ -390,7 +414,7 @@ def sample_ddpm(n_sample, diff_net, vae_net, diff_latent_dim, noise_divider=1.0,
     diff_net._calls += 1
     latents = eng.sample(n_sample, nd=noise_divider, multires=(timesteps == "random"), seed=diff_net._seed,
                          call_id=diff_net._calls)
-    samples = vae_net.decode(latents)
+    samples = _decode(eng, vae_net, latents)
     if verbose:
         print(f"Sampling {n_sample}/{n_sample}, Sampling took {np.round((time.time() - start) / 60, 2)} minutes")
     return samples

@@ -611,10 +611,29 @@ def fixture_equal_sparsity(ref=None):
     np.savez_compressed(os.path.join(HERE, "equal_sparsity.npz"), **out)
 
 
+VAE_DECODE_CASES = [(24, 37, 101, 13), (83, 60, 1008, 7), (40, 185, 257, 33), (1, 1, 1, 1), (340, 96, 64, 5)]   # latent, hidden, items, n
+
+
+def fixture_vae_decode(ref):
+    """The reference's own VAE class (train_SDRM.py:206-268) with injected decoder tensors: `vae.decode(z)` (:252-254)."""
+    out = {"n_cases": np.asarray(len(VAE_DECODE_CASES))}
+    for i, (latent, hidden, items, n) in enumerate(VAE_DECODE_CASES):
+        vae = ref.VAE(items, hidden, latent).eval()
+        w1, b1, w2, b2 = synth.synth_vae_decoder(latent, hidden, items, seed=200 + i)
+        with torch.no_grad():
+            vae.decoder[0].weight.copy_(torch.from_numpy(w1)); vae.decoder[0].bias.copy_(torch.from_numpy(b1))
+            vae.decoder[2].weight.copy_(torch.from_numpy(w2)); vae.decoder[2].bias.copy_(torch.from_numpy(b2))
+            z = torch.from_numpy(synth.synth_latents(n, latent, seed=300 + i) * 2.0)
+            y = vae.decode(z)
+        out[f"c{i}_dims"] = np.asarray([latent, hidden, items, n, 200 + i, 300 + i])
+        out[f"c{i}_out"] = y.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "vae_decode.npz"), **out)
+
+
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity", "rank_metrics"]
+    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity", "rank_metrics", "vae_decode"]
     if which == ["equal_sparsity"]:     # numpy only: no need to import the reference
         fixture_equal_sparsity()
         print("wrote equal_sparsity")
@@ -622,7 +641,7 @@ def main():
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
              "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
              "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e,
-             "equal_sparsity": fixture_equal_sparsity, "rank_metrics": fixture_rank_metrics}
+             "equal_sparsity": fixture_equal_sparsity, "rank_metrics": fixture_rank_metrics, "vae_decode": fixture_vae_decode}
     for w in which:
         table[w](ref)
         print("wrote", w)

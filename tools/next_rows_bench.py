@@ -34,6 +34,41 @@ for name, (users, items, q) in {"ML-100k": (843, 1008, 0.937), "ML-1M": (5429, 3
                  "frac_of_8TBps": round(17.0 * n / us / 1e3 / 8000.0, 3), "numpy_cpu_ms": round(cpu_s * 1e3, 1),
                  "speedup": round(cpu_s * 1e6 / us, 1)}
     print(name, res[name], flush=True)
+# ---- VAE decode on the engine, and the fused decode + equal-sparsity chain, against the PyTorch hook + the stand-alone select
+from sdrm_amd.train_SDRM import VAE
+
+
+def timed(fn, reps=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+for name, (latent, hidden, items, users, q) in {"ML-100k": (830, 930, 1008, 843, 0.937), "ML-1M": (340, 600, 3125, 5429, 0.9553),
+                                               "ADM": (40, 200, 8582, 9558, 0.9877)}.items():
+    tensors = [torch.from_numpy(t).cuda() for t in synth.synth_vae_decoder(latent, hidden, items, seed=5)]
+    z = torch.from_numpy(synth.synth_latents(users, latent, seed=6)).cuda()
+    vae = VAE(items, hidden, latent).cuda().eval()
+    with torch.no_grad():
+        for p_, t_ in zip((vae.decoder[0].weight, vae.decoder[0].bias, vae.decoder[2].weight, vae.decoder[2].bias), tensors):
+            p_.copy_(t_)
+        us_torch = timed(lambda: vae.decode(z))
+        us_torch_chain = timed(lambda: e.equal_sparsity(vae.decode(z), q))
+    us_dec = timed(lambda: e.vae_decode(z, *tensors))
+    us_chain = timed(lambda: e.vae_decode_equal_sparsity(z, *tensors, q, keep_raw=False))
+    flops = 2.0 * users * (latent * hidden + hidden * items)
+    res["decode_" + name] = {"users": users, "items": items, "latent": latent, "hidden": hidden,
+                             "engine_decode_us": round(us_dec, 1), "engine_decode_TF": round(flops / us_dec / 1e6, 1),
+                             "torch_decode_us": round(us_torch, 1),
+                             "engine_decode+equal_sparsity_us": round(us_chain, 1), "torch_decode+sdrm_equal_sparsity_us": round(us_torch_chain, 1),
+                             "out_MB": round(users * items * 4 / 1e6, 1)}
+    print("decode", name, res["decode_" + name], flush=True)
 from sdrm_amd import metrics
 for name, (users, items) in {"ML-100k": (843, 1008), "ML-1M": (5429, 3125), "ADM": (9558, 8582)}.items():
     scores = synth.synth_scores(users, items, seed=4)
