@@ -110,6 +110,14 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = lib_path()
+    override = os.environ.get("SDRM_LIB")   # diagnostics only (tools/ab_bench.sh): another build of the same ABI, loaded as it is
+    if override:
+        lib = C.CDLL(os.path.abspath(override))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _LIB = lib
+        return lib
     if _build.is_stale():
         if not build_if_missing:
             what = "is missing" if not os.path.exists(path) else "was built from different sources than csrc/ + include/"

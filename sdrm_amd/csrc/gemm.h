@@ -51,6 +51,8 @@ enum : int {
   EPI_TANH_REV = 6,      // eps_hat = tanh(acc + bias) feeds the DDPM reverse update of the sampler state in place
                          // (k_reverse_update fused: on-device Philox, full-resolution sampling)
   EPI_BIAS_G = 7,        // C = acc + bias[n], bounds-checked into an unpadded caller buffer (VAE decode output layer)
+  EPI_BIAS_ROWTAB = 9,   // C = acc + tab[t(row)][n]: layer 0 of the train step, whose bias + time-embedding term b0 + C0[t] is a
+                         // row of the per-step table B0tab picked by the row's timestep (the stacked passes P, S, Q share t)
   EPI_BIAS_G_HIST = 8    // same, and the first radix-select histogram of the values written (sdrm_vae_decode_equal_sparsity:
                          // the equal-sparsity threshold's first sweep over the [users, items] matrix rides on its producer)
 };
@@ -117,6 +119,9 @@ struct GemmArgs {
   uint32_t rev_seed_lo, rev_seed_hi, rev_call_id; int64_t rev_row0;
   // EPI_BIAS_G_HIST: SelectState::hist[0][0] (2048 bins of the top 11 key bits), integer atomics
   uint32_t* hist;
+  // EPI_BIAS_ROWTAB: `bias` is the table [T+1][ldtab]; stacked row r (< 3 * trow_B) belongs to user r mod trow_B, whose timestep
+  // is trow[user]; pad rows use t = 0
+  const int* trow; int trow_B, ldtab;
 };
 
 __device__ __forceinline__ float prelu_f(float v, float a) { return v > 0.f ? v : a * v; }
@@ -637,6 +642,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
           const int row = rbase + rowoff(r);
           if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = tanh_fast(acc[a][b][r] + bias);
         }
+      } else if (EPI == EPI_BIAS_ROWTAB) {
+        int tt[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
+          const int pass = (row >= p.trow_B) + (row >= 2 * p.trow_B);
+          tt[r] = (row < 3 * p.trow_B) ? p.trow[row - pass * p.trow_B] : 0;
+        }
+        float bt[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) bt[r] = p.bias[(size_t)tt[r] * p.ldtab + col];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = acc[a][b][r] + bt[r];
       } else if (EPI == EPI_BIAS_G || EPI == EPI_BIAS_G_HIST) {
         uint32_t* mine = hs + (lane & 1) * SEL_BINS;
 #pragma unroll

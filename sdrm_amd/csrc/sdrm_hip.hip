@@ -857,7 +857,10 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
   pa.row0 = row0; pa.nd = nd;
   {
-    pa.emb = emb_args(e, false);
+    // the step's tables ride on the staging launch: E (embedding backward), C0^T in the trailing columns of W0c (what the
+    // plain-forward path multiplies the one-hot columns with) and B0tab = b0 + C0[t], which layer 0 below adds per row
+    pa.emb = emb_args(e, true);
+    e->smp_b0_version = e->params_version;
     pa.emb_row0 = B + (MP - 3 * B);
     pa.emb_blocks = e->T + 1;
     const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
@@ -865,10 +868,13 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     HIP_TRY(e, hipGetLastError());
   }
   {
+    // Layer 0 contracts over the latent columns only (K = LP instead of LP + TP: a fifth less work at ML-1M): every row's
+    // time-embedding term is a row of B0tab, added in the epilogue.  The one-hot columns of U stay: the layer-0 weight
+    // gradient multiplies them to deliver dC0.
     GemmArgs a{};
-    a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->b0c;
-    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->K0, st,
-                                                Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)}, cfg)));
+    a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab; a.ldtab = e->WP; a.trow = e->tdev; a.trow_B = B;
+    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_ROWTAB>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
+                                                       Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)}, cfg)));
   }
   int rc = hidden_forward(e, MP, 3 * B, st, cfg);
   if (rc) return rc;
