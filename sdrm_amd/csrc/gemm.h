@@ -467,7 +467,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       }
       __syncthreads();
 #ifdef SDRM_STAMPS
-      if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_pro = __builtin_amdgcn_s_memtime();
+      if (true) t_pro = __builtin_amdgcn_s_memtime();
 #endif
       if (wave_active) rd_all(fa0, fb0, 0);
       __syncthreads();   // stage 0 is overwritten from the first K-step on: every wave must hold its step-0 fragments
@@ -546,7 +546,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       ld(ra1, rb1, 3);
       __syncthreads();
 #ifdef SDRM_STAMPS
-      if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_pro = __builtin_amdgcn_s_memtime();
+      if (true) t_pro = __builtin_amdgcn_s_memtime();
 #endif
       if (wave_active) {
         const float* As = smem;
@@ -574,7 +574,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     }
   }
 #ifdef SDRM_STAMPS
-  if (EPI == EPI_PLAIN || EPI == EPI_SLAB) t_loop = __builtin_amdgcn_s_memtime();
+  t_loop = __builtin_amdgcn_s_memtime();
 #endif
 
   // ------------------------------------------------------------------ epilogue
@@ -691,7 +691,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   }
 
 #ifdef SDRM_STAMPS
-  if ((EPI == EPI_PLAIN || EPI == EPI_SLAB) && p.stamps && tid == 0) {
+  if (p.stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
     unsigned long long* o = p.stamps + 8 * (size_t)bid;
     o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();

@@ -176,6 +176,13 @@ const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? 
 // ---- GEMM launch helpers ----------------------------------------------------------------------
 struct Prof { sdrm_engine* e; int cls; double flops; };
 
+#ifdef SDRM_STAMPS
+unsigned long long* g_wgrad_stamps = nullptr;   // diagnostic build: 8 stamp slots per work-group of the batched wgrad launch
+int g_wgrad_stamps_cap = 0, g_wgrad_stamps_n = 0;
+int g_stamp_class = -1;                         // -1: the batched wgrad launch; else the NT launches of this profile class
+#endif
+
+
 // Tile shapes (tools/gemm_tune.py, profiles/r01_gemm_tile_sweep_c.txt).  K is only ~350 deep, so a work-group is ~22
 // K-steps long and what hides its prologue, epilogue and per-K-step barrier is many co-resident work-groups, not a
 // big tile: 64x64x16 (20 KB of LDS, <= 80 VGPRs -> six per CU) for the large launches, 32x32x32 on the 16-wide MFMA
@@ -235,6 +242,12 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
     hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
     if (st0 != hipSuccess) return st0;
   }
+#ifdef SDRM_STAMPS
+  if (g_wgrad_stamps && g_stamp_class >= 0 && pr.e && pr.cls == g_stamp_class && (int)grid.x <= g_wgrad_stamps_cap) {
+    a.stamps = g_wgrad_stamps;
+    g_wgrad_stamps_n = (int)grid.x;
+  }
+#endif
   SDRM_LAUNCH(pr.e, (gemm_kernel<Cfg, LA, LB, XA, XB, EPI>), grid, dim3(NTHREADS), 0, st, a);
   hipError_t rc = hipGetLastError();
   if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
@@ -297,11 +310,6 @@ struct WgradSpec {
   const float* dC; int lddc, Nout; const float* Act; int ldact, Kin; const float* slopeB; int S, kchunk; float* slab; float* dbias;
 };
 
-#ifdef SDRM_STAMPS
-unsigned long long* g_wgrad_stamps = nullptr;   // diagnostic build: 8 stamp slots per work-group of the batched wgrad launch
-int g_wgrad_stamps_cap = 0, g_wgrad_stamps_n = 0;
-#endif
-
 hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mrows, hipStream_t st, Prof pr) {
   GemmBatch b{};
   b.n = n;
@@ -319,14 +327,14 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     a.tiles_n = tiles_n; a.nblocks = tiles_m * tiles_n; a.nsplits = w[k].S;
     b.start[k] = grid;
 #ifdef SDRM_STAMPS
-    a.stamps = g_wgrad_stamps ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;
+    a.stamps = (g_wgrad_stamps && g_stamp_class < 0) ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;
 #endif
     grid += a.nblocks * ((w[k].S + 7) / 8) * 8;   // a multiple of 8: the XCD of a work-group is the same inside its problem
   }
   b.start[n] = grid;
 #ifdef SDRM_STAMPS
   if (grid > g_wgrad_stamps_cap) for (int k = 0; k < n; ++k) b.p[k].stamps = nullptr;
-  else g_wgrad_stamps_n = grid;
+  else if (g_stamp_class < 0) g_wgrad_stamps_n = grid;
 #endif
   const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
   size_t slot = 0;
@@ -1804,6 +1812,7 @@ int sdrm_debug_gemm(int variant, int cfg, const float* A, const float* B, float*
  * returns the mean microseconds per launch measured with HIP events on `stream`. */
 #ifdef SDRM_STAMPS
 // diagnostic build: stamps of the engine's own batched weight-gradient launch (the last one run)
+extern "C" int sdrm_debug_stamp_class(int cls) { g_stamp_class = cls; return SDRM_OK; }
 extern "C" int sdrm_debug_wgrad_stamps_begin(int max_blocks) {
   if (g_wgrad_stamps) (void)hipFree(g_wgrad_stamps);
   g_wgrad_stamps = nullptr;

@@ -27,6 +27,8 @@ for k in range(int(os.environ.get("WARM", 300))):
     e.train_step(x0, 1e-4, seed=1, step=k)
 torch.cuda.synchronize()
 mb = 16384
+CLS = int(os.environ.get("CLS", "-1"))     # -1: the batched wgrad launch; 0..5: an NT launch class of the train step (0 fwd layer 0,
+lib.sdrm_debug_stamp_class(CLS)            # 1 fwd hidden, 2 fwd out, 3 dgrad: the LAST launch of that class in the step is kept)
 assert lib.sdrm_debug_wgrad_stamps_begin(mb) == 0
 for k in range(3):
     e.train_step(x0, 1e-4, seed=1, step=k)
@@ -41,7 +43,7 @@ life, real = a[:, 3] - a[:, 0], a[:, 5] - a[:, 4]
 clk = np.median(life[real > 0] / real[real > 0]) * 0.1
 t0 = a[:, 4].min()
 wall_us = (a[:, 5].max() - t0) / 100.0
-print(f"B={B} L={L} T={T} H={H}: grid {nb}, {len(a)} working work-groups; launch wall {wall_us:.1f} us; clock {clk:.3f} GHz; lifetime med "
+print(f"class {CLS}: B={B} L={L} T={T} H={H}: grid {nb}, {len(a)} working work-groups; launch wall {wall_us:.1f} us; clock {clk:.3f} GHz; lifetime med "
       f"{np.median(life):.0f} cyc = prologue {np.median(pro):.0f} + loop {np.median(loop):.0f} (p10 {np.percentile(loop, 10):.0f}, p90 {np.percentile(loop, 90):.0f}) "
       f"+ epilogue {np.median(epi):.0f}; mean residency {life.sum() / (wall_us * 1e3 * clk * 256):.2f} per CU")
 hw, xcc = a[:, 6], a[:, 7] & 0xF
@@ -49,7 +51,19 @@ cu = ((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8
 ids, counts = np.unique(cu, return_counts=True)
 print(f"   distinct CUs used {len(ids)}; work-groups per CU: min {counts.min()} med {np.median(counts):.0f} max {counts.max()}; "
       f"histogram {dict(zip(*np.unique(counts, return_counts=True)))}")
-steps = np.maximum(1, np.round(loop / np.median(loop / 1.0) * 1.0))   # placeholder (true K-steps differ per problem)
+if CLS >= 0:
+    # NT launch: which CUs got the half-empty last column tiles (352 = 5.5 x 64)?  bid -> logical tile as xcd_remap does
+    bid = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(mb, 8)[:nb, 3] > 0)[0]
+    n = nb
+    q, r = n >> 3, n & 7
+    x, sl = bid & 7, bid >> 3
+    logical = np.where(x < r, x * (q + 1), r * (q + 1) + (x - r) * q) + sl
+    tiles_n = -(-(-(-L // 32) * 32) // 64)
+    ragged = (logical % tiles_n) == tiles_n - 1
+    per_cu_r = np.array([ragged[cu == c].sum() for c in ids])
+    per_cu_end = np.array([a[cu == c, 5].max() for c in ids])
+    print(f"   half-empty tiles per CU: histogram {dict(zip(*np.unique(per_cu_r, return_counts=True)))}; a CU's last work-group ends at "
+          + ", ".join(f"{k} ragged: {np.median((per_cu_end[per_cu_r == k] - a[:, 4].min()) / 100.0):.1f} us" for k in np.unique(per_cu_r)))
 st, en = (a[:, 4] - t0) / 100.0, (a[:, 5] - t0) / 100.0
 print("   t[us]  alive  started  ended   (whole chip, 10-us bins)")
 for lo in np.arange(0, wall_us + 10.0, 10.0):
