@@ -102,6 +102,8 @@ struct GemmArgs {
   int tiles_n;      // number of tiles along N (grid.x = tiles_m * tiles_n, XCD-swizzled)
   int nblocks;      // tiles_m * tiles_n
   int nsplits;      // K-slices (EPI_SLAB only; 1 otherwise)
+  uint32_t magic_tiles_n, magic_nblocks;   // floor(2^32 / d) + 1 for d = tiles_n / nblocks (0 when d == 1): the work-group's tile
+                    // coordinates come from two scalar multiplies instead of two emulated integer divisions (gemm_magic below)
   const float* bias;
   const float* slopeA;  // PReLU slope applied to A elements on load (XF_PRELU)
   const float* slopeB;
@@ -215,6 +217,12 @@ __device__ __forceinline__ void store_tile_km(float* __restrict__ dst, const flo
 // XCD-aware remap (cdna guide T1, bijective form): hardware deals consecutive block ids round-robin
 // over the 8 XCDs; give every XCD a contiguous range of logical tiles so that the N-tiles of one
 // M-tile (which re-read the same activation rows) share an L2.
+// n / d for 0 <= n, n * d < 2^32, with m = floor(2^32 / d) + 1 (d >= 2) or 0 (d == 1): exact (the error term n * (m * d - 2^32)
+// stays below 2^32).  The launch helpers fill the magics; an emulated 32-bit division is ~25 dependent scalar / vector
+// instructions at the head of every work-group, where nothing else can be issued yet.
+__host__ __device__ __forceinline__ uint32_t gemm_magic(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint32_t)d) + 1u; }
+__device__ __forceinline__ int div_magic(int n, uint32_t m) { return m ? (int)__umulhi((uint32_t)n, m) : n; }
+
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
@@ -261,8 +269,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE];
 #ifdef SDRM_STAMPS
   unsigned long long t_in = __builtin_amdgcn_s_memtime(), t_pro = 0, t_loop = 0;
+  unsigned long long t_ld = 0, t_land = 0;   // -DSDRM_STAMPS=2: inside the NT prologue
   const unsigned long long r_in = __builtin_amdgcn_s_memrealtime();   // 100 MHz: with t_in / t_out gives the clock the chip held
 #endif
+  // Everything the prologue needs from the kernel arguments is requested in ONE batch of scalar loads here (the compiler
+  // otherwise fetches the operand pointers in a third dependent round trip, after the tile coordinates are known): the
+  // empty asm makes the values live at this point.
+  asm volatile("" ::"s"(p.A), "s"(p.B), "s"(p.lda), "s"(p.ldb), "s"(p.K), "s"(p.kchunk), "s"(p.tiles_n), "s"(p.nblocks),
+               "s"(p.magic_tiles_n), "s"(p.limA), "s"(p.limB));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,14 +290,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     // XCDs), so the slice's two operand strips (a few MB) are fetched from HBM once and re-read from that
     // XCD's L2 by the other tiles.  Spread over XCDs they were fetched 4.6x (measured: FETCH_SIZE).
     const int x = bid & 7, slot = bid >> 3;
-    split = (slot / p.nblocks) * 8 + x;
-    logical = slot % p.nblocks;
+    const int q = div_magic(slot, p.magic_nblocks);
+    split = q * 8 + x;
+    logical = slot - q * p.nblocks;
     if (split >= p.nsplits) return;
   } else {
     logical = xcd_remap(bid, p.nblocks);
     split = 0;
   }
-  const int tile_m = logical / p.tiles_n, tile_n = logical - tile_m * p.tiles_n;
+  const int tile_m = div_magic(logical, p.magic_tiles_n), tile_n = logical - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kb = split * p.kchunk;
   const int ke = min(kb + p.kchunk, p.K);
@@ -452,8 +467,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       if constexpr (Cfg::PF == 2) {
         ld(ra0, rb0, 0);
         ld(ra1, rb1, 1);
+#if defined(SDRM_STAMPS) && SDRM_STAMPS == 2
+        t_ld = __builtin_amdgcn_s_memtime();     // setup done, first loads issued
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if constexpr (EPI == EPI_TANH_REV) rev_draw();   // VALU work under the first loads' round trip
         st(ra0, rb0, 0);
+#if defined(SDRM_STAMPS) && SDRM_STAMPS == 2
+        __builtin_amdgcn_sched_barrier(0);
+        t_land = __builtin_amdgcn_s_memtime();   // the first K-step's operands have landed and sit in LDS
+#endif
         ld(ra0, rb0, 2);
         st(ra1, rb1, 1);
         ld(ra1, rb1, 3);
@@ -697,8 +720,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     o[0] = t_in; o[1] = t_pro; o[2] = t_loop; o[3] = __builtin_amdgcn_s_memtime();
     o[4] = r_in; o[5] = __builtin_amdgcn_s_memrealtime();
     // where the work-group ran: HW_REG_HW_ID (id 4: cu_id bits 11:8, sh_id 12, se_id 15:13) and HW_REG_XCC_ID (id 20)
+#if SDRM_STAMPS == 2
+    o[6] = t_ld; o[7] = t_land;
+#else
     o[6] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));
     o[7] = (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+#endif
   }
 #endif
   if (EPI == EPI_BIAS_G_HIST) {

@@ -231,6 +231,7 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
   a.tiles_n = tiles_n;
   a.nblocks = tiles_m * tiles_n;
   a.nsplits = splits;
+  a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
   dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * ((splits + 7) / 8) * 8) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
   const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
@@ -325,6 +326,7 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     a.dbias = w[k].dbias; a.dbias_stride = w[k].Nout;
     const int tiles_m = (w[k].Nout + Cfg0::BM - 1) / Cfg0::BM, tiles_n = (w[k].Kin + Cfg0::BN - 1) / Cfg0::BN;
     a.tiles_n = tiles_n; a.nblocks = tiles_m * tiles_n; a.nsplits = w[k].S;
+    a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
     b.start[k] = grid;
 #ifdef SDRM_STAMPS
     a.stamps = (g_wgrad_stamps && g_stamp_class < 0) ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;

@@ -28,6 +28,10 @@ for cfg in [int(c) for c in os.environ.get("CFGS", "0,1").split(",")]:
               f"lifetime med {np.median(life):.0f} cyc = prologue {np.median(pro):.0f} (p90 {np.percentile(pro, 90):.0f}) + loop {np.median(loop):.0f} "
               f"(p90 {np.percentile(loop, 90):.0f}) + epilogue {np.median(epi):.0f}; sum of lifetimes / (wall x clock x 256 CUs) = "
               f"{life.sum() / (wall_us * 1e3 * clk * 256):.2f} resident work-groups per CU", flush=True)
+        if os.environ.get("FINE") and v == 0:   # -DSDRM_STAMPS=2 build: slots 6 / 7 = first loads issued / first K-step landed in LDS
+            print(f"      prologue split: entry -> first loads issued {np.median(a[:, 6] - a[:, 0]):.0f} (p90 {np.percentile(a[:, 6] - a[:, 0], 90):.0f}) cyc, "
+                  f"-> first K-step landed {np.median(a[:, 7] - a[:, 6]):.0f} (p90 {np.percentile(a[:, 7] - a[:, 6], 90):.0f}), "
+                  f"-> fragments read, both barriers {np.median(a[:, 1] - a[:, 7]):.0f} (p90 {np.percentile(a[:, 1] - a[:, 7], 90):.0f})")
         if os.environ.get("TIMELINE") and M >= 5000 and v == 0:
             t0 = a[:, 4].min()
             st, en = (a[:, 4] - t0) / 100.0, (a[:, 5] - t0) / 100.0
