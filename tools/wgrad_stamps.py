@@ -59,7 +59,10 @@ if CLS >= 0:
     x, sl = bid & 7, bid >> 3
     logical = np.where(x < r, x * (q + 1), r * (q + 1) + (x - r) * q) + sl
     tiles_n = -(-(-(-L // 32) * 32) // 64)
-    ragged = (logical % tiles_n) == tiles_n - 1
+    tn = logical % tiles_n
+    if os.environ.get("ROTN"):            # the -DSDRM_ROTN experiment rotates the N-tile order by the row tile
+        tn = (tn + (logical // tiles_n)) % tiles_n
+    ragged = tn == tiles_n - 1
     per_cu_r = np.array([ragged[cu == c].sum() for c in ids])
     per_cu_end = np.array([a[cu == c, 5].max() for c in ids])
     print(f"   half-empty tiles per CU: histogram {dict(zip(*np.unique(per_cu_r, return_counts=True)))}; a CU's last work-group ends at "
