@@ -192,10 +192,10 @@ typedef TileCfg<64, 64, 2, 2, 4, 32, 32, 1> Cfg1;  //  64x 64x32, one prefetch s
 typedef TileCfg<64, 128, 2, 2, 4, 16> Cfg2;    //  64x128x16
 typedef TileCfg<128, 128, 2, 2, 4, 16> Cfg3;   // 128x128x16
 typedef TileCfg<32, 32, 2, 2, 4, 32, 16> Cfg4; //  32x 32x32 on v_mfma_f32_16x16x4_f32 (NT launches of <= 4096 rows)
-typedef TileCfg<192, 64, 2, 2, 3, 16> Cfg5;    // 192x 64x16: three 32x32 accumulators per wave, three work-groups per CU (experiment)
-constexpr int N_TILE_CFGS = 6;
-const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32, 192};
-const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32, 64};
+constexpr int N_TILE_CFGS = 5;   // (a 192x64x16 tile - exactly one round of three fat work-groups per CU at 24576 x 352 - measured 3 % slower:
+                                 //  profiles/r02_gemm_stagger_and_waveflip.txt)
+const int kCfgBM[N_TILE_CFGS] = {64, 64, 64, 128, 32};
+const int kCfgBN[N_TILE_CFGS] = {64, 64, 128, 128, 32};
 constexpr int FUSE_REV_MAX_ROWS = 4096;   // = the launches that run on the 32x32 tile (4 accumulator rows per lane: two Philox calls);
                                           // measured (tools/shard_probe.py): 679 / 1358 / 2715 rows 21.1 / 24.9 / 36.6 -> 18.8 / 22.6 / 33.7 us per step;
                                           // on the 64x64 tile (16 rows per lane) 5429 rows 54.3 -> 56.9
@@ -263,9 +263,6 @@ hipError_t launch_gemm(GemmArgs& a, int M, int N, int splits, hipStream_t st, Pr
     case 2: return launch_gemm_cfg<Cfg2, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     case 3: return launch_gemm_cfg<Cfg3, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
     case 4: return launch_gemm_cfg<Cfg4, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
-    case 5:
-      if constexpr (LA == LD_KCONTIG && LB == LD_KCONTIG) return launch_gemm_cfg<Cfg5, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
-      else return launch_gemm_cfg<Cfg0, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);   // the tall tile exists for NT launches only
     default: return launch_gemm_cfg<Cfg0, LA, LB, XA, XB, EPI>(a, M, N, splits, st, pr);
   }
 }
@@ -1786,7 +1783,7 @@ int sdrm_debug_gemm(int variant, int cfg, const float* A, const float* B, float*
   hipStream_t st = (hipStream_t)stream;
   // The kernel reads whole tiles without bounds checks, so stage the caller's matrices in zero-padded
   // scratch (test hook only: allocates and synchronises).
-  const int Mp = round_up(M, 384), Np = round_up(N, 128), Kp = round_up(K, 128);   // 384: whole tiles of every row granule (64, 128, 192)
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
   const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;     // A as stored: [M,K] or [K,M]
   const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;     // B as stored: [N,K] or [K,N]
   float *dA = nullptr, *dB = nullptr, *dC = nullptr;
@@ -1837,7 +1834,7 @@ extern "C" int sdrm_debug_wgrad_stamps_read(unsigned long long* host_out, int ma
 extern "C" int sdrm_debug_gemm_stamps(int variant, int cfg, int M, int N, int K, unsigned long long* host_out, int max_blocks,
                                       int warm) {
   if (cfg < 0 || cfg >= N_TILE_CFGS) return SDRM_ERR_ARG;
-  const int Mp = round_up(M, 384), Np = round_up(N, 128), Kp = round_up(K, 128);   // 384: whole tiles of every row granule (64, 128, 192)
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
   const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
   const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;
   float *dA = nullptr, *dB = nullptr, *dC = nullptr;
@@ -1866,7 +1863,7 @@ extern "C" int sdrm_debug_gemm_stamps(int variant, int cfg, int M, int N, int K,
 int sdrm_debug_gemm_time(int variant, int cfg, int M, int N, int K, int reps, float* us_out, void* stream) {
   if (!us_out || reps < 1 || M % 32 || N % 32 || K % 32 || variant < 0 || variant > 2 || cfg < 0 || cfg >= N_TILE_CFGS) return SDRM_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  const int Mp = round_up(M, 384), Np = round_up(N, 128), Kp = round_up(K, 128);   // 384: whole tiles of every row granule (64, 128, 192)
+  const int Mp = round_up(M, 128), Np = round_up(N, 128), Kp = round_up(K, 128);
   const int ar = variant == 2 ? Kp : Mp, ac = variant == 2 ? Mp : K;
   const int br = variant == 0 ? Np : Kp, bc = variant == 0 ? K : Np;
   float *dA = nullptr, *dB = nullptr, *dC = nullptr;

@@ -11,7 +11,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdrm_amd import _lib  # noqa: E402
 
 lib = _lib.load()
-# cfg 5 = 192x64x16 (three accumulators per wave, three work-groups per CU): exactly one round at 24576 rows x 352 columns
 SHAPES = [  # (variant, M, N, K, label)    variant 0: A[M,K]*B[N,K]^T   1: A[M,K]*B[K,N]   2: A[K,M]^T*B[K,N]
     (0, 24576, 352, 448, "train fwd L0  B=8192"),
     (0, 24576, 352, 352, "train fwd hid B=8192"),
