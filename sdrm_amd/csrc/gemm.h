@@ -53,6 +53,9 @@ enum : int {
   EPI_BIAS_G = 7,        // C = acc + bias[n], bounds-checked into an unpadded caller buffer (VAE decode output layer)
   EPI_BIAS_ROWTAB = 9,   // C = acc + tab[t(row)][n]: layer 0 of the train step, whose bias + time-embedding term b0 + C0[t] is a
                          // row of the per-step table B0tab picked by the row's timestep (the stacked passes P, S, Q share t)
+  EPI_BIAS_PRELU = 10,   // C = prelu(acc + bias[n]; slopeE): the sampler's hidden layers store the ACTIVATION - nothing reads their
+                         // pre-activations again (no backward), and the next layer then loads its operand without the PReLU-on-load
+                         // transform, which costs the 5429-row launches ~1.5 us each (12.7 us plain against 16 us with it)
   EPI_BIAS_G_HIST = 8    // same, and the first radix-select histogram of the values written (sdrm_vae_decode_equal_sparsity:
                          // the equal-sparsity threshold's first sweep over the [users, items] matrix rides on its producer)
 };
@@ -607,6 +610,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   auto rowoff = [](int r) { return (MF == 32) ? (r & 3) + 8 * (r >> 2) : r; };
   float slope_sum = 0.f;
   const float slopeE = (EPI == EPI_DPRELU) ? *p.slopeE : 0.f;
+  const float slopeP = (EPI == EPI_BIAS_PRELU) ? *p.slopeE : 0.f;
   float* __restrict__ Cp = p.C;
   // EPI_BIAS_G_HIST: the main loop is over (its last K-step ended in a barrier), so the operand stages become two copies
   // of the 2048-bin digit histogram (lane parity picks the copy: halves the same-address serialisation on the hot bins)
@@ -627,13 +631,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G || EPI == EPI_TANH_REV || EPI == EPI_BIAS_G ||
-          EPI == EPI_BIAS_G_HIST)
+          EPI == EPI_BIAS_G_HIST || EPI == EPI_BIAS_PRELU)
         bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int row = rbase + rowoff(r);
           Cp[(size_t)row * p.ldc + col] = acc[a][b][r] + bias;
+        }
+      } else if (EPI == EPI_BIAS_PRELU) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const int row = rbase + rowoff(r);
+          Cp[(size_t)row * p.ldc + col] = prelu_f(acc[a][b][r] + bias, slopeP);
         }
       } else if (EPI == EPI_BIAS_TANH) {
         float y[NR];

@@ -501,10 +501,20 @@ int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hi
 
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
 // (its bias / K differ between training and sampling).
-int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, int r0 = 0, int cls = PC_FWD_HIDDEN) {
+// post_act (the sampler): every buffer holds the layer's ACTIVATION - the producer's epilogue applied PReLU, the operand is
+// loaded as it is; otherwise (training, which needs the pre-activations for its backward) PReLU is applied on operand load.
+int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, int r0 = 0, int cls = PC_FWD_HIDDEN,
+                   bool post_act = false) {
   const double fl = 2.0 * rows * (double)e->W * e->W;
   const size_t ro = (size_t)r0 * e->WP;
   for (int k = 1; k <= e->H; ++k) {
+    if (post_act) {
+      GemmArgs a{};
+      a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = e->bhc; a.slopeE = slope_ptr(e, k);
+      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, pre_buf(e, k - 1) + ro, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
+                                                         Prof{e, cls, fl}, cfg)));
+      continue;
+    }
     GemmArgs a{};
     a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = e->bhc; a.slopeA = slope_ptr(e, k - 1);
     HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS>(a, pre_buf(e, k - 1) + ro, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
@@ -1455,12 +1465,13 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       const int rows = s1 - s0, MP = round_up(rows, BM);
       const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows);
       {
+        // the sampler keeps ACTIVATIONS in the layer buffers (EPI_BIAS_PRELU): no backward will ask for the pre-activations
         GemmArgs a{};
-        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP;
-        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS>(a, e->Us + (size_t)s0 * e->LP, e->LP, e->W0c, e->K0, MP, e->WP, e->LP, sc,
-                                                    Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)}, cfg)));
+        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP; a.slopeE = slope_ptr(e, 0);
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, e->Us + (size_t)s0 * e->LP, e->LP, e->W0c, e->K0, MP, e->WP, e->LP, sc,
+                                                          Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)}, cfg)));
       }
-      int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN);
+      int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN, true);
       if (rc) return rc;
       float c1, sqrt_alpha, sqrt_beta;
       reverse_coeffs(e, i, c1, sqrt_alpha, sqrt_beta);
@@ -1477,12 +1488,12 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
           a.rev_c1 = c1; a.rev_sqrt_alpha = sqrt_alpha; a.rev_sqrt_beta = sqrt_beta; a.rev_nd = s.nd;
           a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
           a.rev_row0 = s.row0;
-          HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
-                                                           e->LP, e->WP, sc, pr, cfg)));
+          HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+                                                          e->LP, e->WP, sc, pr, cfg)));
           continue;
         }
-        HIP_TRY(e, (gemm_forward<XF_PRELU, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
-                                                          e->LP, e->WP, sc, pr, cfg)));
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+                                                         e->LP, e->WP, sc, pr, cfg)));
       }
       ReverseArgs ra{};
       ra.X = e->X; ra.Y = e->Y; ra.U = e->Us;
