@@ -231,7 +231,7 @@ def pmc_traffic(kernel_class: str, lib_hash: str):
     the value is dropped when the file was collected from other kernel sources than the library loaded now."""
     import re
     path = _profile_file("*pmc_traffic.json")
-    m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
+    m = re.search(r"<(\d+),(\d+),(\d+),(\d+),(\d+)>", kernel_class)
     if not path or not m:
         return None, {"file": None}
     data = json.load(open(path))
@@ -257,7 +257,7 @@ def pmc_mfma_busy(kernel_class: str, lib_hash: str):
     None when that pass belongs to other kernel sources."""
     import re
     path = _profile_file("*pmc_sq.json")
-    m = re.search(r"<(\d),(\d),(\d),(\d),(\d)>", kernel_class)
+    m = re.search(r"<(\d+),(\d+),(\d+),(\d+),(\d+)>", kernel_class)
     if not path or not m:
         return None
     data = json.load(open(path))

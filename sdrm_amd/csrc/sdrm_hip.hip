@@ -129,13 +129,13 @@ enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, P
                  PC_SMP_OUT, PC_COUNT };
 // the template arguments are <LOADA,LOADB,XFA,XFB,EPI> of gemm_kernel (what rocprofv3 prints after the tile type)
 static const char* kProfNames[PC_COUNT] = {
-    "train: gemm_kernel<0,0,0,0,0> fwd layer0 (bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
+    "train: gemm_kernel<0,0,0,0,9> fwd layer0 (row-table bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
     "train: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)",
     "train: gemm_kernel<0,0,0,0,3> dgrad (prelu' epilogue)",
     "train: gemm_batch_kernel<1,1,0,1,4> wgrad of all layers in one launch (prelu-in, split-K slabs)",
     "train: gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)",
-    "sample: gemm_kernel<0,0,0,0,0> fwd layer0 (bias table)", "sample: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
-    "sample: gemm_kernel<0,0,1,0,1> fwd out (prelu-in, tanh)"};
+    "sample: gemm_kernel<0,0,0,0,10> fwd layer0 (bias table, prelu epilogue)", "sample: gemm_kernel<0,0,0,0,10> fwd hidden (bias, prelu epilogue)",
+    "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)"};
 
 namespace {
 
