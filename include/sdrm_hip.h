@@ -175,7 +175,9 @@ int sdrm_sample(sdrm_engine* e, int n, float noise_divider, int multires, int mo
                 const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,
                 int64_t row0, float* out, int64_t* Tj_out, void* stream);
 
-/* The same loop in resumable form (sdrm_sample == begin + steps(all) + end).  The EXPLICIT-mode
+/* The same loop in resumable form (sdrm_sample == begin + steps(all) + end).  A sampling call uses the parameters as
+ * they are at sdrm_sample_begin (the sampler reads its own snapshot of the net): sdrm_set_params or train steps issued
+ * between its sdrm_sample_steps calls do not change its result.  The EXPLICIT-mode
  * pointers must stay valid until sdrm_sample_end.  sdrm_sample_steps runs at most `count` reverse
  * steps; sdrm_sample_remaining returns the next step index i (0 = loop finished). */
 int sdrm_sample_begin(sdrm_engine* e, int n, float noise_divider, int multires, int mode, const float* xT,

@@ -98,8 +98,12 @@ struct sdrm_engine {
   size_t dec_cap[7] = {0, 0, 0, 0, 0, 0, 0};
   Exchange xch;                      // RCCL communicator of the user-sharded step (sdrm_comm_init_rank / sdrm_allreduce_init)
   mutable int64_t n_launches = 0;    // kernel launches issued through this handle since sdrm_create
-  uint64_t params_version = 0;       // bumped whenever the parameters change (set_params, Adam)
-  uint64_t smp_b0_version = 0;       // parameters the sampler's bias table B0tab was built from
+  // The sampler's own copy of everything it reads of the net (padded weights, biases, the folded bias table b0 + C0[i], the two
+  // PReLU slopes), taken by sdrm_sample_begin: a sampling call is a function of the parameters at its begin, whatever
+  // sdrm_set_params or train steps do between its sdrm_sample_steps calls (the persistent narrow-net sampler, one launch
+  // for the whole loop, has that property by construction).
+  float* smp_w = nullptr;
+  size_t smp_off[7] = {0, 0, 0, 0, 0, 0, 0};   // W0c, Whc, Woc, bhc, boc, B0tab, slopes
   struct SampleStateT {
     bool active; int n, MP, multires, mode, i_next; float nd; const float* z; const uint8_t* keep;
     uint64_t seed, call_id; int64_t row0;
@@ -503,16 +507,24 @@ int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hi
 // (its bias / K differ between training and sampling).
 // post_act (the sampler): every buffer holds the layer's ACTIVATION - the producer's epilogue applied PReLU, the operand is
 // loaded as it is; otherwise (training, which needs the pre-activations for its backward) PReLU is applied on operand load.
+// what a forward reads of the net: the live compute copies, or the sampler's snapshot of them
+struct NetView { const float *W0c, *Whc, *Woc, *bhc, *boc, *B0tab, *slope0, *slopeh; };
+NetView snapshot_view(const sdrm_engine* e) {
+  const float* b = e->smp_w;
+  return NetView{b + e->smp_off[0], b + e->smp_off[1], b + e->smp_off[2], b + e->smp_off[3], b + e->smp_off[4], b + e->smp_off[5],
+                 b + e->smp_off[6], b + e->smp_off[6] + 1};
+}
+
 int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, int r0 = 0, int cls = PC_FWD_HIDDEN,
-                   bool post_act = false) {
+                   bool post_act = false, const NetView* nv = nullptr) {
   const double fl = 2.0 * rows * (double)e->W * e->W;
   const size_t ro = (size_t)r0 * e->WP;
   for (int k = 1; k <= e->H; ++k) {
     if (post_act) {
       GemmArgs a{};
-      a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = e->bhc; a.slopeE = slope_ptr(e, k);
-      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, pre_buf(e, k - 1) + ro, e->WP, e->Whc, e->WP, MP, e->WP, e->WP, st,
-                                                         Prof{e, cls, fl}, cfg)));
+      a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = nv ? nv->bhc : e->bhc; a.slopeE = nv ? nv->slopeh : slope_ptr(e, k);
+      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, pre_buf(e, k - 1) + ro, e->WP, nv ? nv->Whc : e->Whc, e->WP, MP, e->WP, e->WP,
+                                                         st, Prof{e, cls, fl}, cfg)));
       continue;
     }
     GemmArgs a{};
@@ -710,6 +722,13 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
+  {
+    const size_t sz[7] = {(size_t)round_up(e->WP, 128) * e->K0, (size_t)round_up(e->WP, 128) * e->WP, (size_t)round_up(e->LP, 128) * e->WP,
+                          (size_t)e->WP, (size_t)e->LP, (size_t)n * e->WP, 4};
+    size_t tot = 0;
+    for (int k = 0; k < 7; ++k) { e->smp_off[k] = tot; tot += (sz[k] + 63) / 64 * 64; }   // 256-byte aligned pieces
+    HIP_TRY(e, dalloc(&e->smp_w, tot));
+  }
   HIP_TRY(e, dalloc(&e->sel, 1));
   HIP_TRY(e, dalloc(&e->one_dev, 4));
   {
@@ -749,7 +768,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -787,7 +806,6 @@ int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (int jr = join_chains(e, st)) return jr;
   HIP_TRY(e, hipMemcpyAsync(e->p, flat, e->P * 4, hipMemcpyDeviceToDevice, st));
-  e->params_version++;
   return launch_adam(e, nullptr, 0.f, 0, st);  // re-pack only
 }
 
@@ -848,7 +866,6 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     // narrow net: tables (B0tab = b0 + C0[t], E for the embedding backward), then staging and all layers in one launch
     int rc = emb_tables(e, true, st);
     if (rc) return rc;
-    e->smp_b0_version = e->params_version;
     SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
     ka.x0 = x0;
     if (mode == SDRM_RNG_EXPLICIT) { ka.noise = rnd->noise; ka.t = rnd->t; ka.keep = rnd->keep; }
@@ -881,7 +898,6 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     // the step's tables ride on the staging launch: E (embedding backward), C0^T in the trailing columns of W0c (what the
     // plain-forward path multiplies the one-hot columns with) and B0tab = b0 + C0[t], which layer 0 below adds per row
     pa.emb = emb_args(e, true);
-    e->smp_b0_version = e->params_version;
     pa.emb_row0 = B + (MP - 3 * B);
     pa.emb_blocks = e->T + 1;
     const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
@@ -1110,7 +1126,6 @@ int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
   if (!e) return SDRM_ERR_ARG;
   if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
   e->adam_t += 1;
-  e->params_version++;
   return launch_adam(e, grad, lr, 1, (hipStream_t)stream);
 }
 
@@ -1341,7 +1356,6 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
   int rc = emb_tables(e, true, st);
   if (rc) return rc;
-  e->smp_b0_version = e->params_version;
   int i_start = T;
   e->smp_nact.assign(T + 2, n);                       // n_act[i] = rows with Tj >= i (all rows when full resolution)
   if (multires) {
@@ -1381,6 +1395,19 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   if (skinny) {
     e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, true, false, i_start};
     return SDRM_OK;
+  }
+  {
+    // the call's snapshot of the net (see sdrm_engine::smp_w)
+    float* b = e->smp_w;
+    auto cp = [&](int k, const float* src, size_t n_) { return src ? hipMemcpyAsync(b + e->smp_off[k], src, n_ * 4, hipMemcpyDeviceToDevice, st) : hipSuccess; };
+    HIP_TRY(e, cp(0, e->W0c, (size_t)e->WP * e->K0));
+    HIP_TRY(e, cp(1, e->H >= 1 ? e->Whc : nullptr, (size_t)e->WP * e->WP));
+    HIP_TRY(e, cp(2, e->Woc, (size_t)e->LP * e->WP));
+    HIP_TRY(e, cp(3, e->H >= 1 ? e->bhc : nullptr, (size_t)e->WP));
+    HIP_TRY(e, cp(4, e->boc, (size_t)e->LP));
+    HIP_TRY(e, cp(5, e->B0tab, (size_t)(T + 1) * e->WP));
+    HIP_TRY(e, hipMemcpyAsync(b + e->smp_off[6], slope_ptr(e, 0), 4, hipMemcpyDeviceToDevice, st));
+    if (e->H >= 1) HIP_TRY(e, hipMemcpyAsync(b + e->smp_off[6] + 1, slope_ptr(e, 1), 4, hipMemcpyDeviceToDevice, st));
   }
   SampleInitArgs ia{};
   ia.xT = xT; ia.keep = keep; ia.Tj = multires ? e->Tj_dev : nullptr; ia.rowid = multires ? e->rowid_dev : nullptr;
@@ -1443,13 +1470,9 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   // waiting for its backward is gone.
   e->fwd_done = false;
   e->bwd_begun = false;
-  // Train steps may run between sdrm_sample_steps calls (bench.py interleaves them): the weights' compute copies follow
-  // Adam by themselves, the folded bias table b0 + C0[i] is rebuilt here when the parameters moved since it was made.
-  if (e->smp_b0_version != e->params_version) {
-    int rc = emb_tables(e, true, st);
-    if (rc) return rc;
-    e->smp_b0_version = e->params_version;
-  }
+  // Train steps may run between sdrm_sample_steps calls (bench.py interleaves them): the sampler reads its own snapshot of
+  // the net (sdrm_sample_begin), so they change nothing of this call.
+  const NetView nv = snapshot_view(e);
   if (e->n_chains > 1 && !e->chains_pending) {       // fork: the other chains start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
     for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
@@ -1467,18 +1490,18 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       {
         // the sampler keeps ACTIVATIONS in the layer buffers (EPI_BIAS_PRELU): no backward will ask for the pre-activations
         GemmArgs a{};
-        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = e->B0tab + (size_t)i * e->WP; a.slopeE = slope_ptr(e, 0);
-        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, e->Us + (size_t)s0 * e->LP, e->LP, e->W0c, e->K0, MP, e->WP, e->LP, sc,
+        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = nv.B0tab + (size_t)i * e->WP; a.slopeE = nv.slope0;
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, e->Us + (size_t)s0 * e->LP, e->LP, nv.W0c, e->K0, MP, e->WP, e->LP, sc,
                                                           Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)}, cfg)));
       }
-      int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN, true);
+      int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN, true, &nv);
       if (rc) return rc;
       float c1, sqrt_alpha, sqrt_beta;
       reverse_coeffs(e, i, c1, sqrt_alpha, sqrt_beta);
       const bool fused = !s.multires && s.mode == SDRM_RNG_PHILOX && (e->tune.fuse_rev == 2 || (e->tune.fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
       {
         GemmArgs a{};
-        a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = e->boc; a.slopeA = slope_ptr(e, e->H);
+        a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = nv.boc;
         a.rows_valid = MP; a.cols_valid = e->LP;
         const Prof pr{e, PC_SMP_OUT, 2.0 * rows * (double)e->L * e->W};
         if (fused) {
@@ -1488,11 +1511,11 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
           a.rev_c1 = c1; a.rev_sqrt_alpha = sqrt_alpha; a.rev_sqrt_beta = sqrt_beta; a.rev_nd = s.nd;
           a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
           a.rev_row0 = s.row0;
-          HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+          HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
                                                           e->LP, e->WP, sc, pr, cfg)));
           continue;
         }
-        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, e->Woc, e->WP, MP,
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
                                                          e->LP, e->WP, sc, pr, cfg)));
       }
       ReverseArgs ra{};

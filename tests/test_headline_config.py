@@ -190,10 +190,9 @@ def test_sampling_headline_philox(engine_cls, sample_case, multires, tile, fused
 
 
 def test_sampling_interleaved_with_train_steps(engine_cls, sample_case):
-    """bench.py walks train steps between sdrm_sample_steps calls.  The sampler keeps its own state, so with the
-    parameters restored after each train step the interleaved run must reproduce the uninterrupted one bit for bit;
-    with the parameters left to move, the folded layer-0 bias table has to follow them (it is rebuilt), which the
-    oracle checks at a small size in tests/test_hip_parity.py."""
+    """bench.py walks train steps between sdrm_sample_steps calls.  The sampler keeps its own state and its own snapshot
+    of the net, so the interleaved run - the parameters moving under it with every Adam step - must reproduce the
+    uninterrupted one bit for bit at the measured size."""
     c = sample_case["philox"]
     flat = synth.flatten_params(sample_case["init"], H)
     x0 = synth.synth_latents(2048, L, seed=8)
@@ -204,9 +203,8 @@ def test_sampling_interleaved_with_train_steps(engine_cls, sample_case):
     e.sample_begin(N_SAMPLE, nd=ND, seed=c["seed"], call_id=c["call_id"], row0=c["row0"])
     k = 0
     while e.sample_steps(7) > 0:
-        e.train_step(x0, 1e-4, seed=3, step=k)     # clobbers the shared activation buffers, moves the parameters
-        e.set_params(flat)
+        e.train_step(x0, 1e-3, seed=3, step=k)     # clobbers the shared activation buffers, moves the parameters
         k += 1
     out = e.sample_end()
-    assert bool((out == ref).all())
+    assert k >= 10 and bool((out == ref).all())
     e.close()

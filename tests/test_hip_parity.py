@@ -390,10 +390,12 @@ def test_skinny_sampler_vs_oracle(engine_cls, dims, multires):
     e.close()
 
 
-def test_sampler_follows_parameters_between_calls(engine_cls, tile):
-    """Train steps may run between sdrm_sample_steps calls (bench.py interleaves them).  On the per-layer path the later
-    reverse steps use the new parameters in every layer - including the folded layer-0 bias table b0 + C0[i], which is
-    rebuilt when the parameters moved (a stale table was ADVICE r1) - and a forward waiting for its backward is dropped."""
+def test_sampling_call_uses_the_parameters_of_its_begin(engine_cls, tile):
+    """Train steps may run between sdrm_sample_steps calls (bench.py interleaves them).  A sampling call is a function of
+    the parameters at sdrm_sample_begin: the sampler reads its own snapshot of the net (weights, biases, the folded layer-0
+    bias table b0 + C0[i], slopes), so parameters that move later - set_params, Adam - change nothing of the running call
+    (a stale bias table beside fresh weights was ADVICE r1), and a train forward waiting for its backward is dropped
+    because the sampler runs through the activation buffers it lived in."""
     from oracle import sdrm_oracle as orc
     from sdrm_amd.engine import SdrmError
     L, W, T, H, n, cut = 96, 80, 10, 1, 50, 6
@@ -410,20 +412,19 @@ def test_sampler_follows_parameters_between_calls(engine_cls, tile):
     e._sample_n = n
     assert e.sample_steps(T - cut) == cut
     eps, t, masks = synth.synth_train_randoms(n, L, T, 1.0, seed=44)
-    e.train_forward(synth.synth_latents(n, L, seed=45), noise=eps, t=t, keep=masks)
-    e.set_params(synth.flatten_params(init_b, H))
+    x0 = synth.synth_latents(n, L, seed=45)
+    e.train_step(x0, 1e-2, noise=eps, t=t, keep=masks)          # Adam moves every parameter
+    e.set_params(synth.flatten_params(init_b, H))               # and then they are replaced altogether
+    e.train_forward(x0, noise=eps, t=t, keep=masks)
     assert e.sample_steps(T) == 0
     with pytest.raises(SdrmError):
         e.train_backward()          # the sampler ran through the buffers that forward lived in
     out = e.sample_end()
-    oa, ob = orc.Oracle(L, W, T, H, init_a), orc.Oracle(L, W, T, H, init_b)
-    x = torch.from_numpy(xT).clone()
-    for i in range(T, 0, -1):
-        o = oa if i > cut else ob
-        eps_hat = o.forward(x, torch.full((n,), i, dtype=torch.int64), torch.from_numpy(keep[i]).float())
-        zi = torch.from_numpy(z[i]) if i > 1 else torch.zeros_like(x)
-        x = orc.reverse_update(x, eps_hat, zi, i, o.beta, o.alpha, o.alphabar)
-    assert close(out, x.numpy()), rel_max(out.cpu().numpy(), x.numpy())
+    ref = orc.Oracle(L, W, T, H, init_a).sample(xT, z, keep)
+    assert close(out, ref.numpy()), rel_max(out.cpu().numpy(), ref.numpy())
+    # the next call sees the new parameters
+    out_b = e.sample(n, xT=xT, z=z, keep=keep)
+    assert close(out_b, orc.Oracle(L, W, T, H, init_b).sample(xT, z, keep).numpy())
     e.close()
 
 
