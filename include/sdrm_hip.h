@@ -208,6 +208,10 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream);
  * ALGORITHMIC flops (2*rows*N*K on the unpadded dims).  Adds two event records per launch, so it is
  * used in a separate pass, never inside the throughput-timed region. */
 int sdrm_profile_begin(sdrm_engine* e, int capacity);
+/* Restricts the bracketing to ONE kernel class (cls < 0: all classes again).  Every bracketed launch puts two marker packets on
+ * the stream, and the markers of neighbouring launches inflate each other's intervals (+3..5 us per launch, +10 us on the
+ * largest one): bench.py finds the dominant class with all classes bracketed, then times that class alone. */
+int sdrm_profile_only(sdrm_engine* e, int cls);
 int sdrm_profile_end(sdrm_engine* e, void* stream);
 int sdrm_profile_classes(void);
 const char* sdrm_profile_name(int cls);

@@ -118,6 +118,7 @@ struct sdrm_engine {
   // event profiling (bench only)
   bool prof_on = false;
   int prof_cap = 0;
+  int prof_only = -1;                   // >= 0: only launches of this class are bracketed (sdrm_profile_only)
   std::vector<hipEvent_t> prof_ev;      // 2 per recorded launch
   std::vector<int> prof_cls;
   std::vector<double> prof_flops;
@@ -239,7 +240,7 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
   a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
   dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * ((splits + 7) / 8) * 8) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
-  const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
+  const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == pr.cls);
   size_t slot = 0;
   if (rec) {
     slot = e->prof_cls.size();
@@ -343,7 +344,7 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
   if (grid > g_wgrad_stamps_cap) for (int k = 0; k < n; ++k) b.p[k].stamps = nullptr;
   else if (g_stamp_class < 0) g_wgrad_stamps_n = grid;
 #endif
-  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap;
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == pr.cls);
   size_t slot = 0;
   if (rec) {
     slot = e->prof_cls.size();
@@ -1785,6 +1786,12 @@ int sdrm_profile_begin(sdrm_engine* e, int capacity) {
   e->prof_flops.clear();
   for (int i = 0; i < 16; ++i) { e->prof_ms[i] = 0; e->prof_fl[i] = 0; e->prof_n[i] = 0; }
   e->prof_on = true;
+  return SDRM_OK;
+}
+
+int sdrm_profile_only(sdrm_engine* e, int cls) {
+  if (!e || cls >= PC_COUNT) return SDRM_ERR_ARG;
+  e->prof_only = cls < 0 ? -1 : cls;
   return SDRM_OK;
 }
 

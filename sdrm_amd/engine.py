@@ -263,7 +263,13 @@ class Engine:
         return int(self.lib.sdrm_launch_count(self._h))
 
     # ------------------------------------------------------------------ profiling (bench only)
-    def profile_begin(self, capacity=4096):
+    def profile_begin(self, capacity=4096, only=None):
+        """`only`: name of the one kernel class to bracket (as `profile_end` returns them); None = every GEMM launch."""
+        cls = -1
+        if only is not None:
+            names = [self.lib.sdrm_profile_name(c).decode() for c in range(self.lib.sdrm_profile_classes())]
+            cls = names.index(only)
+        self._check(self.lib.sdrm_profile_only(self._h, cls), "sdrm_profile_only")
         self._check(self.lib.sdrm_profile_begin(self._h, int(capacity)), "sdrm_profile_begin")
 
     def profile_end(self):
