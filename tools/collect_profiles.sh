@@ -11,8 +11,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-echo "bench done"
+: > "$OUT/bench.err"
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > "$OUT/bench_20_5.json" 2>> "$OUT/bench.err"
 echo "bench 20/5 done"
 cd /tmp
@@ -27,6 +26,12 @@ echo "sq done"
 cd "$ROOT"
 python3 tools/pmc_sq.py "$OUT/pmc_sq" "$OUT/pmc_sq.json" > "$OUT/pmc_sq.txt"
 python3 tools/pmc_summary.py "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_traffic.json" > "$OUT/pmc_traffic.txt"
+# the headline line last: it replays `traffic` / MFMA-busy from the PMC summaries just made (bench.py reads profiles/*pmc_*.json
+# and drops them unless they carry the hash of the library it loaded)
+cp "$OUT/pmc_traffic.json" "$ROOT/profiles/${TAG}_pmc_traffic.json"
+cp "$OUT/pmc_sq.json" "$ROOT/profiles/${TAG}_pmc_sq.json"
+python3 bench.py > "$OUT/bench.json" 2>> "$OUT/bench.err"
+echo "bench done"
 CFGS=0,1,2,4 python3 tools/gemm_tune.py > "$OUT/gemm_tile_sweep.txt" 2>&1
 # keep the merge small: the per-dispatch PMC CSVs are large
 find "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" -name "*.csv" -size +8M -delete || true
