@@ -5,14 +5,18 @@
 import ctypes as C, os, numpy as np
 lib = C.CDLL(os.environ.get("STAMPLIB", "tools/libsdrm_stamps.so"))
 lib.sdrm_debug_gemm_stamps.restype = C.c_int
-K = 2240
+K = int(os.environ.get('K', 2240))
+RS = [int(v) for v in os.environ.get('RS', '1,2,3,4,5,6,7,8').split(',')]
+WARM = int(os.environ.get('WARM', 200))
 for v, name in ((2, "wgrad loop (k-major fragments, ds_read_b32)"), (0, "NT loop (k-minor fragments, ds_read_b128)")):
     print(name)
-    for r in (1, 2, 3, 4, 5, 6, 7, 8):
+    for r in RS:
         M, N = 1024, 1024 * r
+        if os.environ.get('MN'):   # e.g. MN=16384,64: every work-group streams its own A columns (no sharing through L2)
+            M, N = (int(v) * (r if i == 0 else 1) for i, v in enumerate(os.environ['MN'].split(',')))
         mb = 4096
         buf = (C.c_ulonglong * (8 * mb))()
-        nb = lib.sdrm_debug_gemm_stamps(v, 0, M, N, K, buf, mb, 200)
+        nb = lib.sdrm_debug_gemm_stamps(v, 0, M, N, K, buf, mb, WARM)
         if nb <= 0:
             print(f"  r={r}: n/a ({nb})"); continue
         a = np.frombuffer(buf, dtype=np.uint64).reshape(mb, 8)[:nb].astype(np.int64)
