@@ -335,7 +335,25 @@ def main():
     # N > 1 over RCCL: the exchange is issued by the library itself (sdrm_train_step_sharded); --exchange torch keeps the
     # torch.distributed collectives between the three phases (the only form a gloo rehearsal can run)
     use_abi = world > 1 and args.exchange == "rccl-abi" and args.backend == "nccl"
-    trainer = RcclTrainer(eng, rank, world) if use_abi else ShardedTrainer(eng, rank, world)
+    trainer, exchange_used = None, ("none" if world == 1 else "torch.distributed between the phases")
+    if use_abi:
+        # every rank must end up on the same exchange: a rank whose communicator could not be made takes all of them to the
+        # torch.distributed form (the line says so) rather than leaving the N-GPU run without a number
+        why = ""
+        try:
+            trainer = RcclTrainer(eng, rank, world)
+        except Exception as ex:
+            why = f"{type(ex).__name__}: {ex}"
+        ok = torch.tensor([1 if trainer is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.cpu()) == 1:
+            exchange_used = "RCCL inside libsdrm_hip.so (sdrm_train_step_sharded)"
+        else:
+            trainer = None
+            exchange_used = "torch.distributed between the phases (sdrm_comm_init_rank failed on a rank" + (": " + why if why else "") + ")"
+            print("bench.py: " + exchange_used, file=sys.stderr)
+    if trainer is None:
+        trainer = ShardedTrainer(eng, rank, world)
     job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
 
     def barrier():
@@ -457,8 +475,7 @@ def main():
                        "global_batch": B, "n_sample": n, "step_mix": f"{n_train} train : {T} sample per job cycle",
                        "timed_train_steps": round(kinds["train"], 3), "timed_sample_steps": round(kinds["sample"], 3),
                        "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
-                       "collectives": ((("RCCL issued by libsdrm_hip.so (sdrm_train_step_sharded)" if use_abi else
-                                         f"torch.distributed/{args.backend} between the C-ABI phases")
+                       "collectives": ((exchange_used + f" [{args.backend}]"
                                         + ": all-reduce of 5 f64 loss sums + flat f32 gradient in two buckets per train step")
                                        if world > 1 else "none")},
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),

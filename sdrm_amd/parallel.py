@@ -82,9 +82,16 @@ class RcclTrainer:
     def __init__(self, engine, rank: int = 0, world: int = 1, unique_id: bytes | None = None, group=None):
         self.engine, self.rank, self.world = engine, rank, world
         if unique_id is None:
-            box = [type(engine).comm_unique_id() if rank == 0 else None]
+            box = [None]
+            if rank == 0:
+                try:   # a failure here must still reach the broadcast, or the other ranks wait for it for ever
+                    box[0] = type(engine).comm_unique_id()
+                except Exception as ex:
+                    box[0] = ex
             if world > 1:
                 dist.broadcast_object_list(box, src=0, group=group)
+            if isinstance(box[0], Exception):
+                raise box[0]
             unique_id = box[0]
         engine.comm_init_rank(world, rank, unique_id)
 
