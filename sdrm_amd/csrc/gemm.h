@@ -289,14 +289,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
 
   int logical, split;
   if (EPI == EPI_SLAB) {
-    // split-K launch: all tiles of one K-slice go to ONE XCD (blocks are dealt round-robin over the 8
-    // XCDs), so the slice's two operand strips (a few MB) are fetched from HBM once and re-read from that
-    // XCD's L2 by the other tiles.  Spread over XCDs they were fetched 4.6x (measured: FETCH_SIZE).
-    const int x = bid & 7, slot = bid >> 3;
-    const int q = div_magic(slot, p.magic_nblocks);
-    split = q * 8 + x;
-    logical = slot - q * p.nblocks;
-    if (split >= p.nsplits) return;
+    // split-K launch: the (slice, tile) units, slice-major, are dealt to the 8 XCDs in contiguous runs (work-groups go
+    // round-robin over the XCDs, xcd_remap undoes that), so the tiles of one K-slice sit on one XCD - two when a run ends
+    // inside the slice - and the slice's two operand strips (a few MB) are fetched from HBM once and re-read from that
+    // XCD's L2 by the other tiles.  Spread over XCDs they were fetched 4.6x (measured: FETCH_SIZE).  Any slice count fills
+    // all XCDs evenly (round 1 dealt whole slices, s -> XCD s mod 8, and needed a multiple of 8).
+    const int total = p.nblocks * p.nsplits;
+    if (bid >= total) return;   // a batched launch pads every problem's range to a multiple of 8
+    const int u = xcd_remap(bid, total);
+    split = div_magic(u, p.magic_nblocks);
+    logical = u - split * p.nblocks;
   } else {
     logical = xcd_remap(bid, p.nblocks);
     split = 0;

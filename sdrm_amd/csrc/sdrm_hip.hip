@@ -49,7 +49,7 @@ struct Tuning {
   int nt32_max_rows_train = 8192;  // SDRM_NT32_MAX_ROWS_TRAIN: the same for the train step's launches (stacked rows = 3 x batch):
                                  // 6144 stacked rows (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile,
                                  // 12288 a tie; the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
-  int wgrad_blocks = 1024;       // SDRM_WGRAD_BLOCKS: work-groups a wgrad launch aims for
+  int wgrad_blocks = 2816;       // SDRM_WGRAD_BLOCKS: work-groups the batched weight-gradient launch of a step aims for (2.2 rounds of 5 per CU)
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
 };
 
@@ -238,7 +238,7 @@ hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st
   a.nblocks = tiles_m * tiles_n;
   a.nsplits = splits;
   a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
-  dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * ((splits + 7) / 8) * 8) : (unsigned)a.nblocks, 1, 1);
+  dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * splits) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
   const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == pr.cls);
   size_t slot = 0;
@@ -337,7 +337,7 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
 #ifdef SDRM_STAMPS
     a.stamps = (g_wgrad_stamps && g_stamp_class < 0) ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;
 #endif
-    grid += a.nblocks * ((w[k].S + 7) / 8) * 8;   // a multiple of 8: the XCD of a work-group is the same inside its problem
+    grid += round_up(a.nblocks * w[k].S, 8);   // a multiple of 8: the XCD of a work-group is the same inside its problem
   }
   b.start[n] = grid;
 #ifdef SDRM_STAMPS
@@ -360,32 +360,29 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
   return rc;
 }
 
-void pick_splits(const Tuning& tn, int Mrows, int Nout, int Kin, int& S, int& kchunk) {
-  const int c = pick_cfg(tn);
-  const int tiles = ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
+// Split-K plan of a backward's weight gradients: ONE slice count for all of them (so the one-call and the two-call backward
+// add the same partial sums in the same order), chosen so that the batched launch has about `wgrad_blocks` work-groups:
+// 2.2 rounds of what the device holds at once (5 work-groups per CU, 1280 on MI355X).  Measured on one box, train step in
+// us (profiles/r02_wgrad_slices_any_count.txt): ML-1M, 114 tiles: 11 slices (one round) 572, 22 / 24 slices 573 / 573,
+// 10 / 12 / 13 slices (just under / over a round) 586-588, 21 / 23: 577 / 581; ML-100k, 702 tiles: 4 slices 356, 3: 359,
+// 1-2: 361, 8 (round 1's multiple of 8): 369.  2816 gives 24 and 4.  The (slice, tile) units are dealt to the XCDs in
+// contiguous runs (gemm.h), so any slice count fills the chip evenly.
+void pick_splits(const Tuning& tn, int Mrows, int tiles_total, int& S, int& kchunk) {
   const int BK = 32;
-  int want = tn.wgrad_blocks / tiles;  // floor: never exceed the target (a 513th block would add a whole round)
-  int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps per block
+  int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps of 32 rows per work-group
   if (max_by_rows < 1) max_by_rows = 1;
-  S = want < 1 ? 1 : want;
+  S = tn.wgrad_blocks / (tiles_total < 1 ? 1 : tiles_total);   // floor: never exceed the target (one block more is a round more)
+  if (S < 1) S = 1;
+  if (tn.wgrad_slices > 0) S = tn.wgrad_slices;
   if (S > S_MAX) S = S_MAX;
   if (S > max_by_rows) S = max_by_rows;
-  // K-slices are dealt to the 8 XCDs (a slice's tiles share one L2): a slice count that is not a multiple of 8 leaves
-  // XCDs idle for a whole round (ML-100k, 6 slices: 419 us per train step against 394 with 8).  Take the nearest
-  // multiple of 8 that the rows allow and that survives the rounding of the chunk length.
-  if (S >= 4 && max_by_rows >= 8) {
-    int s8 = (S + 4) / 8 * 8;
-    if (s8 < 8) s8 = 8;
-    const int cap = std::min(S_MAX, max_by_rows) / 8 * 8;
-    if (s8 > cap) s8 = cap;
-    for (int c = s8; c >= 8; c -= 8) {
-      const int kc = round_up((Mrows + c - 1) / c, BK);
-      if (((Mrows + kc - 1) / kc) % 8 == 0) { S = c; break; }
-    }
-  }
-  if (tn.wgrad_slices > 0) S = std::min(tn.wgrad_slices, max_by_rows);
   kchunk = round_up((Mrows + S - 1) / S, BK);
   S = (Mrows + kchunk - 1) / kchunk;
+}
+
+int wgrad_tiles(const Tuning& tn, int Nout, int Kin) {
+  const int c = pick_cfg(tn);
+  return ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
 }
 
 void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks, float* gdst = nullptr) {
@@ -626,7 +623,7 @@ int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
 
 int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice) {
   if (!slices || !rows_per_slice || rows < 1 || n_out < 1 || k_in < 1) return SDRM_ERR_ARG;
-  pick_splits(Tuning{}, rows, n_out, k_in, *slices, *rows_per_slice);
+  pick_splits(Tuning{}, rows, wgrad_tiles(Tuning{}, n_out, k_in), *slices, *rows_per_slice);
   return SDRM_OK;
 }
 
@@ -959,9 +956,9 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     HIP_TRY(e, hipGetLastError());
   }
   int S0, SH, SO, kc0, kcH, kcO;
-  pick_splits(e->tune, MP, e->WP, e->K0, S0, kc0);
-  pick_splits(e->tune, MP, e->WP, e->WP, SH, kcH);
-  pick_splits(e->tune, MP, e->LP, e->WP, SO, kcO);
+  pick_splits(e->tune, MP, wgrad_tiles(e->tune, e->WP, e->K0) + H * wgrad_tiles(e->tune, e->WP, e->WP) + wgrad_tiles(e->tune, e->LP, e->WP),
+              S0, kc0);
+  SH = SO = S0; kcH = kcO = kc0;
   // every dgrad writes [MP,WP]: one tile shape for all of them, so the slope partial counts agree
   const int cfg_d = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);
   const int cfg_w = pick_cfg(e->tune);   // tile of every split-K launch of this backward (backward_wgrads reuses it)

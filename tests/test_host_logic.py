@@ -84,9 +84,9 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
                                              (2560, 64, 160), (512, 352, 352), (3072, 352, 352), (12288, 352, 352),
                                              (64, 32, 32), (135040, 96, 96), (192, 4096, 4096)])
 def test_wgrad_split_plan(rows, n_out, k_in):
-    """Split-K planning of a weight-gradient launch (host logic only): the slices cover the rows, are whole K-steps,
-    and come in multiples of 8 (one per XCD) whenever eight slices of >= 128 rows exist and the output is small
-    enough to want at least four."""
+    """Split-K planning of a weight-gradient launch (host logic only): the slices cover the rows with no empty slice, are
+    whole K-steps of 32 rows, at least four of them per slice when the rows allow, and slices x tiles stays within the
+    work-group target (2.2 rounds of the resident work-groups) unless one slice already exceeds it."""
     lib = _lib.load()
     s, kc = ctypes.c_int(), ctypes.c_int()
     assert lib.sdrm_debug_plan_wgrad(rows, n_out, k_in, ctypes.byref(s), ctypes.byref(kc)) == 0
@@ -94,8 +94,10 @@ def test_wgrad_split_plan(rows, n_out, k_in):
     assert 1 <= S <= 64 and KC % 32 == 0 and KC >= 32
     assert S * KC >= rows and (S - 1) * KC < rows                 # covers the rows, no empty slice
     tiles = -(-n_out // 64) * -(-k_in // 64)
-    if rows // 128 >= 8 and 1024 // tiles >= 4:
-        assert S % 8 == 0, (S, KC)
+    assert S == 1 or S * tiles <= 2816, (S, tiles)
+    assert S == 1 or KC >= 128, (S, KC)
+    if tiles * 2 <= 2816 and rows >= 256:
+        assert S >= 2, (S, KC)                                     # a small gradient over many rows is split
     assert lib.sdrm_debug_plan_wgrad(0, 8, 8, ctypes.byref(s), ctypes.byref(kc)) == -1
 
 
