@@ -176,9 +176,10 @@ int sdrm_sample(sdrm_engine* e, int n, float noise_divider, int multires, int mo
                 int64_t row0, float* out, int64_t* Tj_out, void* stream);
 
 /* The same loop in resumable form (sdrm_sample == begin + steps(all) + end).  A sampling call uses the parameters as
- * they are at sdrm_sample_begin (the sampler reads its own snapshot of the net): sdrm_set_params or train steps issued
- * between its sdrm_sample_steps calls do not change its result.  The EXPLICIT-mode
- * pointers must stay valid until sdrm_sample_end.  sdrm_sample_steps runs at most `count` reverse
+ * they are at sdrm_sample_begin (the sampler reads its own snapshot of the net; a narrow net's whole reverse loop is one launch
+ * that sdrm_sample_begin itself issues): sdrm_set_params or train steps issued after the begin, between its sdrm_sample_steps
+ * calls, do not change its result.  The streams of the begin / steps / end calls of one sampling call must be the same or
+ * ordered by the caller.  The EXPLICIT-mode pointers must stay valid until sdrm_sample_end.  sdrm_sample_steps runs at most `count` reverse
  * steps; sdrm_sample_remaining returns the next step index i (0 = loop finished). */
 int sdrm_sample_begin(sdrm_engine* e, int n, float noise_divider, int multires, int mode, const float* xT,
                       const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,

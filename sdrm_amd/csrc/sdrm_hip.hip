@@ -101,7 +101,7 @@ struct sdrm_engine {
   // The sampler's own copy of everything it reads of the net (padded weights, biases, the folded bias table b0 + C0[i], the two
   // PReLU slopes), taken by sdrm_sample_begin: a sampling call is a function of the parameters at its begin, whatever
   // sdrm_set_params or train steps do between its sdrm_sample_steps calls (the persistent narrow-net sampler, one launch
-  // for the whole loop, has that property by construction).
+  // for the whole loop, is issued by sdrm_sample_begin itself and so reads the parameters of that moment).
   float* smp_w = nullptr;
   size_t smp_off[7] = {0, 0, 0, 0, 0, 0, 0};   // W0c, Whc, Woc, bhc, boc, B0tab, slopes
   struct SampleStateT {
@@ -1335,6 +1335,44 @@ int sdrm_perturb_input(sdrm_engine* e, const float* x, const int64_t* t, const f
   return SDRM_OK;
 }
 
+// The narrow-net sampler: ONE persistent launch runs the whole reverse loop (rows are independent across all timesteps).  It is
+// issued by sdrm_sample_begin, on that call's stream, so the call reads the parameters as they are at its begin - the same
+// contract as the snapshot of the per-layer path; sdrm_sample_steps is then only book-keeping for the resumable API.
+static int launch_skinny_sampler(sdrm_engine* e, hipStream_t st) {
+  SampleState& s = e->smp;
+  const int n = s.n, L = e->L;
+  SkinnyArgs ka{};
+  ka.W0c = e->W0c; ka.K0 = e->K0; ka.Whc = e->Whc; ka.Woc = e->Woc; ka.bh = e->bhc; ka.bo = e->boc;
+  ka.B0tab = e->B0tab; ka.slope0 = slope_ptr(e, 0); ka.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
+  ka.rev = e->rev_dev; ka.xT = s.xT; ka.Z = s.z; ka.keep = s.keep;
+  ka.Tj = s.multires ? e->Tj_dev : nullptr; ka.rowid = s.multires ? e->rowid_dev : nullptr;
+  ka.out = e->X; ka.n = n; ka.L = L; ka.W = e->W; ka.T = e->T; ka.H = e->H;
+  ka.mode = s.mode; ka.seed_lo = (uint32_t)s.seed; ka.seed_hi = (uint32_t)(s.seed >> 32);
+  ka.call_id = (uint32_t)s.call_id; ka.row0 = s.row0; ka.nd = s.nd;
+  ka.LPs = e->LP; ka.WPs = e->WP;
+  const int NL = (L + 15) / 16, NW = (e->W + 15) / 16;           // tiles with real columns (1..4 each)
+  dim3 grid((n + 15) / 16), block(64 * (NL > NW ? NL : NW));   // 16 rows per work-group, one wave per column tile
+#define SKINNY_LAUNCH(nl, nw) SDRM_LAUNCH(e, (k_skinny_sample<nl, nw>), grid, block, 0, st, ka)
+#define SKINNY_ROW(nl)                                 \
+switch (NW) {                                        \
+  case 1: SKINNY_LAUNCH(nl, 1); break;               \
+  case 2: SKINNY_LAUNCH(nl, 2); break;               \
+  case 3: SKINNY_LAUNCH(nl, 3); break;               \
+  default: SKINNY_LAUNCH(nl, 4); break;              \
+}
+  switch (NL) {
+    case 1: SKINNY_ROW(1); break;
+    case 2: SKINNY_ROW(2); break;
+    case 3: SKINNY_ROW(3); break;
+    default: SKINNY_ROW(4); break;
+  }
+#undef SKINNY_ROW
+#undef SKINNY_LAUNCH
+  HIP_TRY(e, hipGetLastError());
+  s.skinny_launched = true;
+  return SDRM_OK;
+}
+
 int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, const float* xT, const float* z,
                       const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id, int64_t row0,
                       int64_t* Tj_out, void* stream) {
@@ -1392,7 +1430,9 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   const bool skinny = skinny_net(e);
   if (skinny) {
     e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, true, false, i_start};
-    return SDRM_OK;
+    const int rc = launch_skinny_sampler(e, st);
+    if (rc != SDRM_OK) e->smp.active = false;
+    return rc;
   }
   {
     // the call's snapshot of the net (see sdrm_engine::smp_w)
@@ -1430,37 +1470,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   if (s.skinny) {
     // One persistent launch runs the whole reverse loop (rows are independent across all timesteps); the
     // step counter is then only book-keeping for the resumable API.
-    if (!s.skinny_launched) {
-      SkinnyArgs ka{};
-      ka.W0c = e->W0c; ka.K0 = e->K0; ka.Whc = e->Whc; ka.Woc = e->Woc; ka.bh = e->bhc; ka.bo = e->boc;
-      ka.B0tab = e->B0tab; ka.slope0 = slope_ptr(e, 0); ka.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
-      ka.rev = e->rev_dev; ka.xT = s.xT; ka.Z = s.z; ka.keep = s.keep;
-      ka.Tj = s.multires ? e->Tj_dev : nullptr; ka.rowid = s.multires ? e->rowid_dev : nullptr;
-      ka.out = e->X; ka.n = n; ka.L = L; ka.W = e->W; ka.T = e->T; ka.H = e->H;
-      ka.mode = s.mode; ka.seed_lo = (uint32_t)s.seed; ka.seed_hi = (uint32_t)(s.seed >> 32);
-      ka.call_id = (uint32_t)s.call_id; ka.row0 = s.row0; ka.nd = s.nd;
-      ka.LPs = e->LP; ka.WPs = e->WP;
-      const int NL = (L + 15) / 16, NW = (e->W + 15) / 16;           // tiles with real columns (1..4 each)
-      dim3 grid((n + 15) / 16), block(64 * (NL > NW ? NL : NW));   // 16 rows per work-group, one wave per column tile
-#define SKINNY_LAUNCH(nl, nw) SDRM_LAUNCH(e, (k_skinny_sample<nl, nw>), grid, block, 0, st, ka)
-#define SKINNY_ROW(nl)                                 \
-  switch (NW) {                                        \
-    case 1: SKINNY_LAUNCH(nl, 1); break;               \
-    case 2: SKINNY_LAUNCH(nl, 2); break;               \
-    case 3: SKINNY_LAUNCH(nl, 3); break;               \
-    default: SKINNY_LAUNCH(nl, 4); break;              \
-  }
-      switch (NL) {
-        case 1: SKINNY_ROW(1); break;
-        case 2: SKINNY_ROW(2); break;
-        case 3: SKINNY_ROW(3); break;
-        default: SKINNY_ROW(4); break;
-      }
-#undef SKINNY_ROW
-#undef SKINNY_LAUNCH
-      HIP_TRY(e, hipGetLastError());
-      s.skinny_launched = true;
-    }
+    if (!s.skinny_launched) return fail(e, SDRM_ERR_STATE, "sdrm_sample_steps: the sampler was not launched");
     s.i_next = s.i_next > count ? s.i_next - count : 0;
     return SDRM_OK;
   }

@@ -428,6 +428,31 @@ def test_sampling_call_uses_the_parameters_of_its_begin(engine_cls, tile):
     e.close()
 
 
+def test_narrow_net_sampling_call_uses_the_parameters_of_its_begin(engine_cls):
+    """The same contract on the narrow-net path (L, W <= 64): its one persistent launch is issued by sdrm_sample_begin, so
+    parameters replaced between the begin and the first sdrm_sample_steps do not reach the call."""
+    from oracle import sdrm_oracle as orc
+    import ctypes as C
+    from sdrm_amd import _lib
+    L, W, T, H, n = 40, 40, 9, 2, 70
+    init_a, init_b = synth.init_params(L, W, T, H, seed=51), synth.init_params(L, W, T, H, seed=52)
+    xT, z, keep, _ = synth.synth_sample_randoms(n, L, T, 1.0, seed=53)
+    e = engine_cls(L, W, T, H, n)
+    e.set_params(synth.flatten_params(init_a, H))
+    xT_d, z_d, keep_d = (torch.from_numpy(a).cuda() for a in (xT, z, keep))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert e.lib.sdrm_sample_begin(e._h, n, 1.0, 0, _lib.RNG_EXPLICIT, C.c_void_p(xT_d.data_ptr()), C.c_void_p(z_d.data_ptr()),
+                                   C.c_void_p(keep_d.data_ptr()), None, 0, 0, 0, None, st) == 0
+    e._sample_n = n
+    e.set_params(synth.flatten_params(init_b, H))
+    assert e.sample_steps(T) == 0
+    out = e.sample_end()
+    assert close(out, orc.Oracle(L, W, T, H, init_a).sample(xT, z, keep).numpy())
+    out_b = e.sample(n, xT=xT, z=z, keep=keep)
+    assert close(out_b, orc.Oracle(L, W, T, H, init_b).sample(xT, z, keep).numpy())
+    e.close()
+
+
 def test_two_engines_keep_their_own_settings(engine_cls):
     """Tile / path selection is per handle (it was process-global): forcing a tile or switching the narrow-net
     kernels on one engine leaves another engine's launches - and therefore its bits - alone."""
