@@ -343,6 +343,40 @@ def test_philox_mode_train(engine_cls, dims):
     e1.close(); e2.close()
 
 
+@pytest.mark.parametrize("slices", [1, 3, 5, 7, 11, 13])
+@pytest.mark.parametrize("dims", [(96, 80, 7, 1, 700), (200, 136, 12, 2, 400), (40, 40, 9, 3, 300)])
+def test_weight_gradients_at_any_slice_count(engine_cls, monkeypatch, dims, slices):
+    """The (K-slice, tile) units of a split-K launch are dealt to the XCDs in contiguous runs, so the slice count need not be
+    a multiple of 8 (round 1) and the planner picks it freely: every count, odd ones and ones that leave a run boundary
+    inside a slice, gives the gradients of the default plan (same sums, another association), in both backward forms."""
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=16), H)
+    x0 = synth.synth_latents(B, L, seed=17)
+    eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=18)
+
+    def grads(two_call):
+        e = engine_cls(L, W, T, H, B)
+        e.set_params(init)
+        e.train_forward(x0, noise=eps, t=t, keep=keep)
+        if two_call:
+            loss = float(e.train_backward_begin().cpu())
+            e.train_backward_finish()
+        else:
+            loss = float(e.train_backward().cpu())
+        g = e.get_grads().cpu().numpy()
+        e.close()
+        return loss, g
+
+    monkeypatch.delenv("SDRM_WGRAD_SLICES", raising=False)
+    l0, g0 = grads(False)
+    monkeypatch.setenv("SDRM_WGRAD_SLICES", str(slices))
+    l1, g1 = grads(False)
+    l2, g2 = grads(True)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert rel_l2(g1, g0) <= 2e-6 and rel_max(g1, g0) <= 2e-5, (rel_l2(g1, g0), rel_max(g1, g0))
+    assert l2 == l1 and np.array_equal(g2, g1)      # the two-call backward adds the same slices in the same order
+
+
 @pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("multires", [False, True])
 def test_philox_mode_sampling(engine_cls, multires, sampler_path, tile, fused):
