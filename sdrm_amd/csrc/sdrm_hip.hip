@@ -951,7 +951,8 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
   sa.part = e->loss_part; sa.nblk = LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
   {
-    dim3 grid((unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256));
+    const unsigned need = (unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256);
+    dim3 grid(std::min(need, 2048u));   // grid-stride beyond: see k_loss_seed
     SDRM_LAUNCH(e, k_loss_seed, grid, dim3(256), 0, st, sa);
     HIP_TRY(e, hipGetLastError());
   }
