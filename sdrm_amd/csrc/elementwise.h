@@ -718,12 +718,23 @@ struct ReverseArgs {
   int s0, n, L, LP, K0, step_i; float c1, sqrt_alpha, sqrt_beta, nd;
   int mode; uint32_t seed_lo, seed_hi, call_id; int64_t row0;
   int bpr;   // work-groups per row (row folded into grid.x)
+  int rpb;   // rows per work-group when a row has at most 128 column quads (then bpr == 1): 340 columns are 85 quads, three
+             // rows fill 255 of the 256 lanes where one row left two thirds of them idle
 };
 
 __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
-  const int rr = blockIdx.x / a.bpr;
+  int rr, q;
+  if (a.rpb > 1) {
+    const int qpr = (a.L + 3) >> 2;
+    const int sub = (int)threadIdx.x / qpr;
+    if (sub >= a.rpb) return;
+    rr = blockIdx.x * a.rpb + sub;
+    q = (int)threadIdx.x - sub * qpr;
+  } else {
+    rr = blockIdx.x / a.bpr;
+    q = (blockIdx.x - rr * a.bpr) * 256 + threadIdx.x;
+  }
   const int s = a.s0 + rr;                       // slot; this launch covers the active slots [s0, n) of one row chain
-  const int q = (blockIdx.x - rr * a.bpr) * 256 + threadIdx.x;
   const int c = 4 * q;
   if (c >= a.L || s >= a.n) return;
   const int r = a.rowid ? a.rowid[s] : s;       // original row: indexes explicit randoms and keys Philox

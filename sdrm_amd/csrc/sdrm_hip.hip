@@ -1538,7 +1538,9 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       ra.mode = s.mode; ra.seed_lo = (uint32_t)s.seed; ra.seed_hi = (uint32_t)(s.seed >> 32);
       ra.call_id = (uint32_t)s.call_id; ra.row0 = s.row0;
       ra.bpr = ((L + 3) / 4 + 255) / 256;
-      SDRM_LAUNCH(e, k_reverse_update, dim3((unsigned)((size_t)ra.bpr * rows)), dim3(256), 0, sc, ra);
+      ra.rpb = std::max(1, 256 / ((L + 3) / 4));
+      const unsigned rev_grid = ra.rpb > 1 ? (unsigned)((rows + ra.rpb - 1) / ra.rpb) : (unsigned)((size_t)ra.bpr * rows);
+      SDRM_LAUNCH(e, k_reverse_update, dim3(rev_grid), dim3(256), 0, sc, ra);
       HIP_TRY(e, hipGetLastError());
     }
   }
