@@ -774,6 +774,24 @@ __global__ __launch_bounds__(256) void k_reverse_update(const ReverseArgs a) {
         make_float4(kp[0] ? 2.f * xn[0] : 0.f, kp[1] ? 2.f * xn[1] : 0.f, kp[2] ? 2.f * xn[2] : 0.f, kp[3] ? 2.f * xn[3] : 0.f);
 }
 
+// Up to eight device-to-device copies in one launch (the sampler's snapshot of the net: eight hipMemcpyAsync calls were eight
+// 5-us nodes on the stream at every sdrm_sample_begin).  Segment = blockIdx.y; float4 body, scalar tail.
+struct CopySegs {
+  const float* src[8]; float* dst[8]; unsigned n[8];
+};
+
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySegs a) {
+  const float* __restrict__ s = a.src[blockIdx.y];
+  float* __restrict__ d = a.dst[blockIdx.y];
+  const unsigned n = a.n[blockIdx.y];
+  if (s == nullptr || n == 0) return;
+  const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+  const unsigned n4 = vec ? n >> 2 : 0;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+  for (unsigned i = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
+
 __global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, float* dst, int n, int L, const int* rowid) {
   const size_t total = (size_t)n * L;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {

@@ -1436,17 +1436,22 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
     return rc;
   }
   {
-    // the call's snapshot of the net (see sdrm_engine::smp_w)
+    // the call's snapshot of the net (see sdrm_engine::smp_w): one launch for all of its pieces
     float* b = e->smp_w;
-    auto cp = [&](int k, const float* src, size_t n_) { return src ? hipMemcpyAsync(b + e->smp_off[k], src, n_ * 4, hipMemcpyDeviceToDevice, st) : hipSuccess; };
-    HIP_TRY(e, cp(0, e->W0c, (size_t)e->WP * e->K0));
-    HIP_TRY(e, cp(1, e->H >= 1 ? e->Whc : nullptr, (size_t)e->WP * e->WP));
-    HIP_TRY(e, cp(2, e->Woc, (size_t)e->LP * e->WP));
-    HIP_TRY(e, cp(3, e->H >= 1 ? e->bhc : nullptr, (size_t)e->WP));
-    HIP_TRY(e, cp(4, e->boc, (size_t)e->LP));
-    HIP_TRY(e, cp(5, e->B0tab, (size_t)(T + 1) * e->WP));
-    HIP_TRY(e, hipMemcpyAsync(b + e->smp_off[6], slope_ptr(e, 0), 4, hipMemcpyDeviceToDevice, st));
-    if (e->H >= 1) HIP_TRY(e, hipMemcpyAsync(b + e->smp_off[6] + 1, slope_ptr(e, 1), 4, hipMemcpyDeviceToDevice, st));
+    CopySegs cs{};
+    auto seg = [&](int i, int k, const float* src, size_t n_, size_t extra = 0) {
+      cs.src[i] = src; cs.dst[i] = b + e->smp_off[k] + extra; cs.n[i] = src ? (unsigned)n_ : 0u;
+    };
+    seg(0, 0, e->W0c, (size_t)e->WP * e->K0);
+    seg(1, 1, e->H >= 1 ? e->Whc : nullptr, (size_t)e->WP * e->WP);
+    seg(2, 2, e->Woc, (size_t)e->LP * e->WP);
+    seg(3, 3, e->H >= 1 ? e->bhc : nullptr, (size_t)e->WP);
+    seg(4, 4, e->boc, (size_t)e->LP);
+    seg(5, 5, e->B0tab, (size_t)(T + 1) * e->WP);
+    seg(6, 6, slope_ptr(e, 0), 1);
+    seg(7, 6, e->H >= 1 ? slope_ptr(e, 1) : nullptr, 1, 1);
+    SDRM_LAUNCH(e, k_copy_segments, dim3(64, 8), dim3(256), 0, st, cs);
+    HIP_TRY(e, hipGetLastError());
   }
   SampleInitArgs ia{};
   ia.xT = xT; ia.keep = keep; ia.Tj = multires ? e->Tj_dev : nullptr; ia.rowid = multires ? e->rowid_dev : nullptr;
@@ -1557,8 +1562,9 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (e->smp.skinny)   // the persistent kernel wrote dense [n,L] rows in original order
     HIP_TRY(e, hipMemcpyAsync(out, e->X, (size_t)e->smp.n * e->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   else
-    SDRM_LAUNCH(e, k_unpad_rows, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->X, e->LP, out,
-                       e->smp.n, e->L, (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
+    SDRM_LAUNCH(e, k_unpad_rows, dim3((unsigned)std::min<size_t>(4096, ((size_t)e->smp.n * e->L + 255) / 256)), dim3(256), 0,
+                (hipStream_t)stream, (const float*)e->X, e->LP, out, e->smp.n, e->L,
+                (const int*)(e->smp.multires ? e->rowid_dev : nullptr));
   HIP_TRY(e, hipGetLastError());
   e->smp.active = false;
   return SDRM_OK;
