@@ -306,6 +306,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--exchange", default="rccl-abi", choices=["rccl-abi", "torch"],
                     help="N > 1: collectives issued inside libsdrm_hip.so over RCCL (default) or by torch.distributed between the phases")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="N = 1 only: run the train steps through sdrm_train_step_sharded over a ONE-rank RCCL communicator (every "
+                         "collective of the N > 1 path is really issued); a rehearsal of that path, not the headline number")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
     args = ap.parse_args()
@@ -352,6 +355,9 @@ def main():
             trainer = None
             exchange_used = "torch.distributed between the phases (sdrm_comm_init_rank failed on a rank" + (": " + why if why else "") + ")"
             print("bench.py: " + exchange_used, file=sys.stderr)
+    if trainer is None and world == 1 and args.rehearse_exchange:
+        trainer = RcclTrainer(eng, 0, 1)
+        exchange_used = "REHEARSAL: RCCL inside libsdrm_hip.so over a one-rank communicator"
     if trainer is None:
         trainer = ShardedTrainer(eng, rank, world)
     job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
@@ -477,7 +483,7 @@ def main():
                        "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
                        "collectives": ((exchange_used + f" [{args.backend}]"
                                         + ": all-reduce of 5 f64 loss sums + flat f32 gradient in two buckets per train step")
-                                       if world > 1 else "none")},
+                                       if (world > 1 or args.rehearse_exchange) else "none")},
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
             "launches_per_step": round(launches_total / prof_steps, 2),

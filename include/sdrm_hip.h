@@ -132,8 +132,9 @@ int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, 
  * No reference counterpart (the reference is single-device, train_SDRM.py:18): rows (users) of the global batch are
  * partitioned over one process per GPU; parameters, Adam state and schedule are replicated.  Per step two things cross
  * GPUs, both as RCCL all-reduce(sum) issued by the library itself: the 5 float64 loss sums (var(R) and both mse means of
- * train_SDRM.py:196-198 are over the GLOBAL batch) and the flat gradient [P], in the two buckets of sdrm_grad_buckets,
- * the first one overlapped with the upper layers' weight gradients on an auxiliary stream.  Sampling needs no exchange.
+ * train_SDRM.py:196-198 are over the GLOBAL batch) and the flat gradient [P] - by default in one all-reduce after the
+ * backward; optionally (sdrm_hip_debug.h) in the two buckets of sdrm_grad_buckets, the first one overlapped with the upper
+ * layers' weight gradients on an auxiliary stream.  Sampling needs no exchange.
  *
  * librccl is loaded at run time (dlopen "librccl.so.1", or $SDRM_RCCL_LIB); a process that already holds one - e.g. a
  * PyTorch process - shares that instance.  Either
@@ -147,8 +148,9 @@ int sdrm_comm_init_rank(sdrm_engine* e, int nranks, int rank, const void* id_hos
 int sdrm_allreduce_init(sdrm_engine* e, void* rccl_comm, void* aux_stream);
 int sdrm_comm_info(const sdrm_engine* e, int* nranks, int* rank);   /* nranks 0 / rank -1: no communicator */
 int sdrm_comm_destroy(sdrm_engine* e);                             /* also done by sdrm_destroy */
-/* sdrm_train_forward (this rank's rows, first global row row0) -> all-reduce of the loss sums -> sdrm_train_backward_begin
- * -> all-reduce of the first bucket beside sdrm_train_backward_finish -> all-reduce of the second bucket -> sdrm_adam_step.
+/* sdrm_train_forward (this rank's rows, first global row row0) -> all-reduce of the loss sums -> sdrm_train_backward ->
+ * all-reduce of the flat gradient -> sdrm_adam_step (two-bucket form: sdrm_train_backward_begin -> all-reduce of the first
+ * bucket beside sdrm_train_backward_finish -> all-reduce of the second bucket -> sdrm_adam_step).
  * `loss` (device float, may be NULL) receives the GLOBAL loss.  With one rank it equals sdrm_train_step bit for bit. */
 int sdrm_train_step_sharded(sdrm_engine* e, const float* x0, int B, int64_t row0, float lr, int mode,
                             const sdrm_train_randoms* rnd, uint64_t seed, uint64_t step, float noise_divider, float* loss,

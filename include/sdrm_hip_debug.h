@@ -44,6 +44,12 @@ int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode);
  * Results do not depend on it (rows are independent and randoms are keyed by row). */
 int sdrm_debug_set_chains(sdrm_engine* e, int chains);
 
+/* Gradient all-reduces of sdrm_train_step_sharded: 1 (default) = one all-reduce of the whole flat gradient after the one-call
+ * backward; 2 = the two buckets of sdrm_grad_buckets, the first overlapped with the upper layers' weight gradients on the
+ * auxiliary stream (pays when the first bucket's all-reduce takes longer than the ~40 us the hand-offs cost); also env
+ * SDRM_AR_BUCKETS.  The result is the same bit for bit. */
+int sdrm_debug_set_gradient_buckets(sdrm_engine* e, int buckets);
+
 /* The engine's ncclComm_t (NULL without one): lets a test hand a communicator made elsewhere to sdrm_allreduce_init. */
 void* sdrm_debug_comm_handle(const sdrm_engine* e);
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "sdrm_perturb_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "sdrm_get_preacts": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "sdrm_profile_begin": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_gradient_buckets": (c_int, [c_void_p, c_int]),
     "sdrm_profile_only": (c_int, [c_void_p, c_int]),
     "sdrm_profile_end": (c_int, [c_void_p, c_void_p]),
     "sdrm_profile_classes": (c_int, []),

@@ -51,6 +51,7 @@ struct Tuning {
                                  // 12288 a tie; the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
   int wgrad_blocks = 2816;       // SDRM_WGRAD_BLOCKS: work-groups the batched weight-gradient launch of a step aims for (2.2 rounds of 5 per CU)
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
+  int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
 };
 
 struct sdrm_engine {
@@ -633,6 +634,12 @@ int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_gradient_buckets(sdrm_engine* e, int buckets) {
+  if (!e || (buckets != 1 && buckets != 2)) return SDRM_ERR_ARG;
+  e->tune.ar_buckets = buckets;
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_chains(sdrm_engine* e, int chains) {
   if (!e) return SDRM_ERR_ARG;
   e->tune.chains = chains;
@@ -687,6 +694,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) e->tune.wgrad_blocks = std::max(1, std::atoi(env));
+  if (const char* env = std::getenv("SDRM_AR_BUCKETS")) e->tune.ar_buckets = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
@@ -1242,6 +1250,19 @@ int sdrm_train_step_sharded(sdrm_engine* e, const float* x0, int B, int64_t row0
   int rc = sdrm_train_forward(e, x0, B, row0, mode, rnd, seed, step, nd, e->sums, stream);
   if (rc) return rc;
   NCCL_TRY(e, api, api->AllReduce(e->sums, e->sums, 5, ncclDouble, ncclSum, x.comm, st));
+  // Default: ONE all-reduce of the whole gradient after the one-call backward (all weight gradients in one batched launch).
+  // The two-bucket form below hides the first bucket's all-reduce behind the upper layers' weight gradients, but its event
+  // hand-offs and split launches cost 36-45 us per step by themselves (one-rank communicator, where the collectives are
+  // free: tools/exchange_probe.py, profiles/r02_exchange_probe.txt) - more than a 0.6 MB all-reduce between GPUs of one
+  // node takes.  sdrm_debug_set_gradient_buckets(e, 2) / SDRM_AR_BUCKETS=2 selects it for nets whose gradient is large
+  // enough for the overlap to pay.
+  const int buckets = e->tune.ar_buckets == 2 ? 2 : 1;
+  if (buckets == 1) {
+    rc = sdrm_train_backward(e, e->sums, nullptr, loss, stream);
+    if (rc) return rc;
+    NCCL_TRY(e, api, api->AllReduce(e->g, e->g, (size_t)e->P, ncclFloat, ncclSum, x.comm, st));
+    return sdrm_adam_step(e, nullptr, lr, stream);
+  }
   rc = sdrm_train_backward_begin(e, e->sums, nullptr, loss, stream);
   if (rc) return rc;
   const int64_t n0 = e->off_a0, n1 = e->P - e->off_a0;

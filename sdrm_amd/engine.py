@@ -72,9 +72,13 @@ class Engine:
             t = torch.from_numpy(np.ascontiguousarray(a)).to(device=self.device, dtype=dtype)
         return t.contiguous()
 
-    def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None):
+    def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None,
+                  gradient_buckets=None):
         """Test / tuning hooks of THIS engine (include/sdrm_hip_debug.h): force a GEMM tile shape (-1 = automatic),
-        switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds."""
+        switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds,
+        the number of gradient all-reduces of the sharded step (1 or 2)."""
+        if gradient_buckets is not None:
+            self._check(self.lib.sdrm_debug_set_gradient_buckets(self._h, int(gradient_buckets)), "sdrm_debug_set_gradient_buckets")
         if tile is not None:
             self._check(self.lib.sdrm_debug_set_tile(self._h, int(tile)), "sdrm_debug_set_tile")
         if skinny is not None:

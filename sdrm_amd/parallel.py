@@ -8,10 +8,11 @@ step, nothing else:
   1. all-reduce(sum) of 5 float64 loss scalars {sum D^2, sum (R-S)^2, sum R, sum R^2, count} after the
      three forwards: var(R) and both mse means of `score_matching_loss` (train_SDRM.py:196-198) are
      over the GLOBAL batch, and the gradient flows through them (Q6).
-  2. all-reduce(sum) of the flat gradient [P] fp32, in two buckets: the upper one (slopes, hidden and output
-     layer) is exchanged while the layer-0 / embedding backward is still running, the lower one right after;
-     every rank then applies the identical Adam update (train_SDRM.py:337), so parameters stay replicated
-     without a broadcast.
+  2. all-reduce(sum) of the flat gradient [P] fp32 after the backward (default), or in two buckets - the first one
+     (embedding + layer 0) exchanged while the upper layers' weight gradients are still being computed, the second right
+     after: the hand-offs of that form cost ~40 us per step by themselves (tools/exchange_probe.py), so it pays only for
+     gradients whose all-reduce takes longer than that; every rank then applies the identical Adam update
+     (train_SDRM.py:337), so parameters stay replicated without a broadcast.
 
 Randomness is Philox keyed by the GLOBAL row index, so G ranks draw exactly what one rank draws.
 Sampling shards users with no communication at all.
@@ -37,7 +38,7 @@ def shard_rows(n_rows: int, rank: int, world: int):
 
 
 class ShardedTrainer:
-    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None, overlap=True):
+    def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None, overlap=False):
         self.engine, self.rank, self.world, self.group, self.overlap = engine, rank, world, group, overlap
         dev = device if device is not None else getattr(engine, "device", "cpu")
         P = n_params if n_params is not None else engine.P

@@ -23,15 +23,17 @@ def engine_cls():
     return Engine
 
 
+@pytest.mark.parametrize("buckets", [1, 2])
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 1024), (40, 40, 93, 5, 107), (96, 72, 10, 0, 33)])
-def test_one_rank_rccl_step_equals_train_step(engine_cls, dims):
+def test_one_rank_rccl_step_equals_train_step(engine_cls, dims, buckets):
     """sdrm_train_step_sharded over a 1-rank RCCL communicator == sdrm_train_step, bit for bit, over three steps
-    (loss, gradient, parameters, Adam moments): the bucketed backward, the in-place all-reduces on the internal gradient
-    and the stream hand-offs change nothing."""
+    (loss, gradient, parameters, Adam moments), in both exchange forms: one all-reduce of the gradient after the backward
+    (default), or the bucketed backward with the first bucket's all-reduce on the auxiliary stream - the in-place
+    all-reduces on the internal gradient and the stream hand-offs change nothing."""
     L, W, T, H, B = dims
     init = synth.flatten_params(synth.init_params(L, W, T, H, seed=61), H)
     x0 = synth.synth_latents(B, L, seed=62)
-    a, b = engine_cls(L, W, T, H, B), engine_cls(L, W, T, H, B)
+    a, b = engine_cls(L, W, T, H, B), engine_cls(L, W, T, H, B).debug_set(gradient_buckets=buckets)
     a.set_params(init); b.set_params(init)
     assert b.comm_info() == (0, -1)
     b.comm_init_rank(1, 0, engine_cls.comm_unique_id())
