@@ -309,6 +309,10 @@ def main():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="N = 1 only: run the train steps through sdrm_train_step_sharded over a ONE-rank RCCL communicator (every "
                          "collective of the N > 1 path is really issued); a rehearsal of that path, not the headline number")
+    ap.add_argument("--rehearse-shard", type=int, default=0, metavar="N",
+                    help="N = 1 only: give this process the rows ONE rank of an N-GPU run would have (B/N users, n/N sampled rows) and run "
+                         "them through the one-rank exchange (implies --rehearse-exchange): that rank's compute plus the launch side of "
+                         "the collectives under the bench protocol, no link time - a projection aid, never the headline number")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
     args = ap.parse_args()
@@ -332,6 +336,10 @@ def main():
     L, W, T, H, B, n = wl["L"], wl["W"], wl["T"], wl["H"], wl["B"], wl["n_sample"]
     row0, rows = shard_rows(B, rank, world)
     srow0, n_local = shard_rows(n, rank, world)
+    if world == 1 and args.rehearse_shard > 1:
+        args.rehearse_exchange = True
+        row0, rows = shard_rows(B, 0, args.rehearse_shard)
+        srow0, n_local = shard_rows(n, 0, args.rehearse_shard)
     eng = Engine(L, W, T, H, max_rows=max(rows, n_local))
     eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
     x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)[row0:row0 + rows]).cuda()
@@ -357,7 +365,8 @@ def main():
             print("bench.py: " + exchange_used, file=sys.stderr)
     if trainer is None and world == 1 and args.rehearse_exchange:
         trainer = RcclTrainer(eng, 0, 1)
-        exchange_used = "REHEARSAL: RCCL inside libsdrm_hip.so over a one-rank communicator"
+        exchange_used = "REHEARSAL: RCCL inside libsdrm_hip.so over a one-rank communicator" + (
+            f", rows of one rank of {args.rehearse_shard} ({rows} users, {n_local} sampled rows)" if args.rehearse_shard > 1 else "")
     if trainer is None:
         trainer = ShardedTrainer(eng, rank, world)
     job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
