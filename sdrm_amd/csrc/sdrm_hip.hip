@@ -49,7 +49,8 @@ struct Tuning {
   int nt32_max_rows_train = 8192;  // SDRM_NT32_MAX_ROWS_TRAIN: the same for the train step's launches (stacked rows = 3 x batch):
                                  // 6144 stacked rows (a 4-GPU shard of the 8192 batch) 234 -> 226 us per step on the 32x32 tile,
                                  // 12288 a tie; the sampling launch of 5429 rows is faster on 64x64 (18.5 k vs 17.5 k steps/s)
-  int wgrad_blocks = 2816;       // SDRM_WGRAD_BLOCKS: work-groups the batched weight-gradient launch of a step aims for (2.2 rounds of 5 per CU)
+  int wgrad_blocks = 2816;       // SDRM_WGRAD_BLOCKS: work-groups the batched weight-gradient launch of a step aims for (2.2 rounds of 5 per CU) ...
+  int wgrad_round = 1280;        // SDRM_WGRAD_ROUND: ... unless ONE round (this many work-groups) already gives eight slices or more
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
   int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
 };
@@ -362,17 +363,21 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
 }
 
 // Split-K plan of a backward's weight gradients: ONE slice count for all of them (so the one-call and the two-call backward
-// add the same partial sums in the same order), chosen so that the batched launch has about `wgrad_blocks` work-groups:
-// 2.2 rounds of what the device holds at once (5 work-groups per CU, 1280 on MI355X).  Measured on one box, train step in
-// us (profiles/r02_wgrad_slices_any_count.txt): ML-1M, 114 tiles: 11 slices (one round) 572, 22 / 24 slices 573 / 573,
-// 10 / 12 / 13 slices (just under / over a round) 586-588, 21 / 23: 577 / 581; ML-100k, 702 tiles: 4 slices 356, 3: 359,
-// 1-2: 361, 8 (round 1's multiple of 8): 369.  2816 gives 24 and 4.  The (slice, tile) units are dealt to the XCDs in
-// contiguous runs (gemm.h), so any slice count fills the chip evenly.
+// add the same partial sums in the same order), chosen so that the batched launch is ONE round of what the device holds at
+// once (5 work-groups per CU, 1280 on MI355X) when that already cuts the reduction eight ways or more, and 2.2 rounds
+// (2816 work-groups) otherwise.  Measured on one box, train step in us (profiles/r02_wgrad_slices_any_count.txt): ML-1M, 114
+// tiles: 11 slices (one round) 572, 22 / 24 slices 573 / 573, 10 / 12 / 13 slices (just under / over a round) 586-588; the
+// same net at the row counts of a 4- / 8-GPU shard: 11 slices 204.0 / 139.7, 24 slices 207.8 / 144.3 (a slice of 128 rows is
+// mostly prologue and epilogue); ML-100k, 702 tiles: 4 slices 356, 3: 359, 1-2: 361, 8 (round 1's multiple of 8): 369.
+// The (slice, tile) units are dealt to the XCDs in contiguous runs (gemm.h), so any slice count fills the chip evenly.
 void pick_splits(const Tuning& tn, int Mrows, int tiles_total, int& S, int& kchunk) {
   const int BK = 32;
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps of 32 rows per work-group
   if (max_by_rows < 1) max_by_rows = 1;
-  S = tn.wgrad_blocks / (tiles_total < 1 ? 1 : tiles_total);   // floor: never exceed the target (one block more is a round more)
+  const int tiles = tiles_total < 1 ? 1 : tiles_total;
+  // one round when that already cuts the reduction eight ways or more, else 2.2 rounds (floor: one block more is a round more)
+  S = tn.wgrad_round / tiles;
+  if (S < 8) S = tn.wgrad_blocks / tiles;
   if (S < 1) S = 1;
   if (tn.wgrad_slices > 0) S = tn.wgrad_slices;
   if (S > S_MAX) S = S_MAX;
@@ -694,6 +699,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_BLOCKS")) e->tune.wgrad_blocks = std::max(1, std::atoi(env));
+  if (const char* env = std::getenv("SDRM_WGRAD_ROUND")) e->tune.wgrad_round = std::max(1, std::atoi(env));
   if (const char* env = std::getenv("SDRM_AR_BUCKETS")) e->tune.ar_buckets = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;

@@ -6,7 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
-CFGS = {"ml1m": (340, 340, 78, 1, 8192), "ml100k": (830, 830, 83, 2, 550), "b160": (340, 340, 78, 1, 160), "adm": (40, 40, 93, 5, 850)}
+CFGS = {"ml1m": (340, 340, 78, 1, 8192), "shard8": (340, 340, 78, 1, 1024), "shard4": (340, 340, 78, 1, 2048), "ml100k": (830, 830, 83, 2, 550), "b160": (340, 340, 78, 1, 160), "adm": (40, 40, 93, 5, 850)}
 L, W, T, H, B = CFGS[os.environ.get("CFG", "ml1m")]
 e = Engine(L, W, T, H, B)
 e.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
