@@ -56,7 +56,7 @@ void* sdrm_debug_comm_handle(const sdrm_engine* e);
 /* Host-side planning of a split-K weight-gradient launch with the default settings (no device work): for a reduction
  * over `rows` stacked rows into ONE [n_out, k_in] gradient, the number of K-slices (slabs) and the rows per slice the
  * engine would use (a step's gradients are planned together: one slice count for all - one round of the resident
- * work-groups when that gives eight slices or more, else about 2.2 rounds).  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows > (slices - 1) *
+ * work-groups when that gives eight slices or more of at most 1024 rows, else about 2.2 rounds).  Invariants: rows_per_slice is a multiple of 32, slices * rows_per_slice >= rows > (slices - 1) *
  * rows_per_slice, slices <= 64, at least four K-steps of 32 rows per slice when the rows allow, and slices * tiles does not
  * exceed the 2816 work-group target unless a single slice already does. */
 int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_per_slice);

@@ -364,20 +364,24 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
 
 // Split-K plan of a backward's weight gradients: ONE slice count for all of them (so the one-call and the two-call backward
 // add the same partial sums in the same order), chosen so that the batched launch is ONE round of what the device holds at
-// once (5 work-groups per CU, 1280 on MI355X) when that already cuts the reduction eight ways or more, and 2.2 rounds
-// (2816 work-groups) otherwise.  Measured on one box, train step in us (profiles/r02_wgrad_slices_any_count.txt): ML-1M, 114
-// tiles: 11 slices (one round) 572, 22 / 24 slices 573 / 573, 10 / 12 / 13 slices (just under / over a round) 586-588; the
-// same net at the row counts of a 4- / 8-GPU shard: 11 slices 204.0 / 139.7, 24 slices 207.8 / 144.3 (a slice of 128 rows is
-// mostly prologue and epilogue); ML-100k, 702 tiles: 4 slices 356, 3: 359, 1-2: 361, 8 (round 1's multiple of 8): 369.
+// once (5 work-groups per CU, 1280 on MI355X) when that cuts the reduction eight ways or more with slices of at most 1024
+// rows, and 2.2 rounds (2816 work-groups) otherwise.  Measured on one box, train step in us
+// (profiles/r02_wgrad_slices_any_count.txt): ML-1M, 114 tiles, 24576 rows: 11 slices (one round) 572, 22 / 24 slices 573 /
+// 573, 10 / 12 / 13 slices (just under / over a round) 586-588 - equal times, but the 2240-row slices of the one-round
+// plan do not fit an XCD's L2 and double the launch's HBM traffic, so this size takes 24; the same net at the row counts
+// of a 4- / 8-GPU shard: 11 slices 204.0 / 139.7, 24 slices 207.8 / 144.3 (a slice of 128 rows is mostly prologue and
+// epilogue); ML-100k, 702 tiles: 4 slices 356, 3: 359, 1-2: 361, 8 (round 1's multiple of 8): 369.
 // The (slice, tile) units are dealt to the XCDs in contiguous runs (gemm.h), so any slice count fills the chip evenly.
 void pick_splits(const Tuning& tn, int Mrows, int tiles_total, int& S, int& kchunk) {
   const int BK = 32;
   int max_by_rows = Mrows / (4 * BK);  // at least 4 K-steps of 32 rows per work-group
   if (max_by_rows < 1) max_by_rows = 1;
   const int tiles = tiles_total < 1 ? 1 : tiles_total;
-  // one round when that already cuts the reduction eight ways or more, else 2.2 rounds (floor: one block more is a round more)
+  // one round when that cuts the reduction eight ways or more AND a slice stays within 1024 rows - the tiles of a slice share
+  // its operand strips through one XCD's 4 MB L2: at 24576 rows 11 slices of 2240 rows take the same 204 us as 24 slices of
+  // 1024 but move 653 MB instead of 334 MB (PMC) - else 2.2 rounds (floor: one block more is a round more)
   S = tn.wgrad_round / tiles;
-  if (S < 8) S = tn.wgrad_blocks / tiles;
+  if (S < 8 || round_up((Mrows + S - 1) / S, BK) > 1024) S = tn.wgrad_blocks / tiles;
   if (S < 1) S = 1;
   if (tn.wgrad_slices > 0) S = tn.wgrad_slices;
   if (S > S_MAX) S = S_MAX;
