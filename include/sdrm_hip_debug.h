@@ -33,6 +33,15 @@ int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train);
 /* Enables (default) / disables the LDS-resident kernels used when the padded widths are <= 64 (csrc/skinny.h,
  * csrc/skinny_train.h); with them off, narrow nets go through the general per-layer GEMM path. */
 int sdrm_debug_set_skinny(sdrm_engine* e, int on);
+/* Row-owned train forward (csrc/rowchain.h: staging, every layer and the loss partial sums of a 96-row group of stacked rows in
+ * ONE work-group per CU; nets with L == W and a padded width of 128..352): 0 never, 1 (default) when the batch fills whole
+ * rounds of the chip (at least 216 groups of 32 users, the last round at least five sixths full), 2 whenever the net allows
+ * (tests); also env SDRM_ROWCHAIN.  A forced tile (sdrm_debug_set_tile) switches it off.  Results agree with the per-layer path
+ * to fp32 summation order; the stacked rows of that step are in the GROUPED order (elementwise.h), which sdrm_get_train_outputs
+ * / sdrm_get_preacts undo.  Refused between sdrm_train_backward_begin and _finish; drops a pending train forward. */
+int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
+/* 1 when this engine's shape qualifies for the row-owned forward (its fragment-packed weight copies exist). */
+int sdrm_debug_rowchain_available(const sdrm_engine* e);
 /* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;
  * every other case uses the stand-alone k_reverse_update): 0 never, 1 (default) for launches of at most 4096 rows - the
  * shards of a multi-GPU run, which run on the 32x32 tile where one launch less per reverse step is worth more than the

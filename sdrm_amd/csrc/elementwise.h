@@ -8,6 +8,17 @@
 
 namespace sdrm {
 
+// Stacked row order of a train step's three passes P, S, Q (train_SDRM.py:331-333).  BLOCKED: pass * B + user, zero rows
+// behind 3 B.  GROUPED (the row-owned forward, rowchain.h): a work-group's 96 rows are the P | S | Q rows of 32 users,
+// row = 96 * (user / 32) + 32 * pass + user % 32; user slots beyond the batch inside the last group, and the rows behind the
+// last group, are padding.
+constexpr int RC_USERS = 32;            // users per group
+constexpr int RC_ROWS = 3 * RC_USERS;   // stacked rows per group
+__host__ __device__ inline int rc_row(int pass, int user) { return RC_ROWS * (user / RC_USERS) + RC_USERS * pass + (user % RC_USERS); }
+__host__ __device__ inline size_t stacked_row(int grouped, int pass, int user, int B) {
+  return grouped ? (size_t)rc_row(pass, user) : (size_t)pass * B + user;
+}
+
 constexpr float MU = 0.1f;          // score_matching_loss(..., mu=.1), :333
 constexpr float MU2 = 0.01f;        // mu ** 2, :196
 
@@ -323,6 +334,7 @@ __global__ __launch_bounds__(256) void k_loss_sums(const double* part, int nblk,
 struct SeedArgs {
   const double* sums; const float* Y; const float* x0; float* dY; float* loss;
   int B, L, LP, MP;
+  int grouped;   // stacked row order (stacked_row above)
   // single-GPU fused step: sums == null and every block folds the k_loss_partials output itself (same reduction tree
   // as k_loss_sums, so the same bits) - one launch less per train step
   const double* part; int nblk; double count;
@@ -354,26 +366,34 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   const float cD = (float)(2.0 * k / N);
   const float cV = (float)(-(0.5 * (A + C) / (den * den)) * 2.0 / (N - 1.0));
   const float rbar = (float)Rbar;
-  const size_t BLP = (size_t)a.B * a.LP;
-  const size_t total = (size_t)(a.B + (a.MP - 3 * a.B)) * QP;
+  // items: user slots (three rows each), then the padding rows behind them (one row each)
+  const int nslots = a.grouped ? RC_USERS * ((a.B + RC_USERS - 1) / RC_USERS) : a.B;
+  const int ntail = a.MP - 3 * nslots;
+  const size_t total = (size_t)(nslots + ntail) * QP;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   // grid-stride (the host caps the grid at 2048 work-groups): the fold above - eight block barriers - is paid once for the
   // two or three column quads a thread then handles (B = 8192: train step 580.5 -> 578.3 us on one box)
   for (size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x; flat < total; flat += (size_t)gridDim.x * 256) {
     const int r = (int)(flat / QP);
     const int c = 4 * (int)(flat - (size_t)r * QP);
-    if (r >= a.B) {
-      const int row = 3 * a.B + (r - a.B);
-      if (row < a.MP) *reinterpret_cast<float4*>(a.dY + (size_t)row * a.LP + c) = zero;
+    if (r >= nslots) {
+      *reinterpret_cast<float4*>(a.dY + (size_t)(3 * nslots + (r - nslots)) * a.LP + c) = zero;
+      continue;
+    }
+    const size_t yP = stacked_row(a.grouped, 0, r, a.B) * a.LP + c, yS = stacked_row(a.grouped, 1, r, a.B) * a.LP + c,
+                 yQ = stacked_row(a.grouped, 2, r, a.B) * a.LP + c;
+    if (r >= a.B) {   // grouped order: a user slot of the last group beyond the batch
+      *reinterpret_cast<float4*>(a.dY + yP) = zero;
+      *reinterpret_cast<float4*>(a.dY + yS) = zero;
+      *reinterpret_cast<float4*>(a.dY + yQ) = zero;
       continue;
     }
     if (r == 0 && c == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);
-    const size_t yi = (size_t)r * a.LP + c;
     float gP[4] = {0.f, 0.f, 0.f, 0.f}, gS[4] = {0.f, 0.f, 0.f, 0.f}, gQ[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < a.L) {
-      const float4 P4 = *reinterpret_cast<const float4*>(a.Y + yi);
-      const float4 S4 = *reinterpret_cast<const float4*>(a.Y + BLP + yi);
-      const float4 Q4 = *reinterpret_cast<const float4*>(a.Y + 2 * BLP + yi);
+      const float4 P4 = *reinterpret_cast<const float4*>(a.Y + yP);
+      const float4 S4 = *reinterpret_cast<const float4*>(a.Y + yS);
+      const float4 Q4 = *reinterpret_cast<const float4*>(a.Y + yQ);
       const float4 X4 = load4_unpadded(a.x0, r, c, a.L);
       const float p_[4] = {P4.x, P4.y, P4.z, P4.w}, s_[4] = {S4.x, S4.y, S4.z, S4.w}, q_[4] = {Q4.x, Q4.y, Q4.z, Q4.w},
                   x_[4] = {X4.x, X4.y, X4.z, X4.w};
@@ -392,9 +412,9 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
         }
       }
     }
-    *reinterpret_cast<float4*>(a.dY + yi) = make_float4(gP[0], gP[1], gP[2], gP[3]);
-    *reinterpret_cast<float4*>(a.dY + BLP + yi) = make_float4(gS[0], gS[1], gS[2], gS[3]);
-    *reinterpret_cast<float4*>(a.dY + 2 * BLP + yi) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
+    *reinterpret_cast<float4*>(a.dY + yP) = make_float4(gP[0], gP[1], gP[2], gP[3]);
+    *reinterpret_cast<float4*>(a.dY + yS) = make_float4(gS[0], gS[1], gS[2], gS[3]);
+    *reinterpret_cast<float4*>(a.dY + yQ) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
   }
 }
 
@@ -526,7 +546,16 @@ struct Job {
   float* gdst; int g_ld;   // where k_grad_finalize writes: flat gradient (g + flat_off, flat_ld) or a scratch table
   float* dst; int dst_ld;                                          // compute copy (may be null)
   float* dstT; int dstT_ld;                                        // transposed compute copy [col][row] (may be null)
+  float* dstF; float* dstFT; int fnct;                             // fragment-packed copies of the matrix / of its transpose for the
+                                                                   // row-owned kernels (rowchain.h; may be null), fnct column tiles
 };
+
+// element (n, k) of a padded row-major [NP][KP] matrix in its fragment-packed copy (rowchain.h): [k / 16][n / 16][lane][k % 4],
+// lane = 16 * ((k / 4) % 4) + n % 16 - one contiguous 1 KiB wave-load per 16-column tile and 16-deep K-step
+__host__ __device__ inline size_t wfrag_index(int n, int k, int NCT) {
+  const int ct = n >> 4, nn = n & 15, ks = k >> 4, kg = (k >> 2) & 3, e = k & 3;
+  return ((((size_t)ks * NCT + ct) * 64) + (size_t)(kg * 16 + nn)) * 4 + e;
+}
 constexpr int MAX_JOBS = 12;
 struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
 
@@ -634,6 +663,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
         if (r < jb.rows && c < jb.cols) {
           w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
           if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+          if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct)] = w;
         }
         tile[ty + 8 * k][tx] = w;
       }
@@ -641,7 +671,10 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (r < jb.rows && c < jb.ncols) jb.dstT[(size_t)c * jb.dstT_ld + r] = tile[tx][ty + 8 * k];
+        if (r < jb.rows && c < jb.ncols) {
+          jb.dstT[(size_t)c * jb.dstT_ld + r] = tile[tx][ty + 8 * k];
+          if (jb.dstFT != nullptr) jb.dstFT[wfrag_index(c, r, jb.fnct)] = tile[tx][ty + 8 * k];
+        }
       }
       __syncthreads();
     }
@@ -652,6 +685,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
     const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
     const float w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
     if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+    if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct)] = w;
   }
 }
 
@@ -801,12 +835,13 @@ __global__ __launch_bounds__(256) void k_unpad_rows(const float* src, int ld, fl
   }
 }
 
-// [3][B][LP] padded outputs -> [3][B][L]
-__global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L, int LP, float* dst) {
+// stacked padded rows (either row order) -> [3][B][L]
+__global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L, int LP, int grouped, float* dst) {
   const size_t total = (size_t)3 * B * L;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / L; const int c = (int)(i - r * L);
-    dst[i] = Y[r * LP + c];
+    const int pass = (int)(r / B), user = (int)(r - (size_t)pass * B);
+    dst[i] = Y[stacked_row(grouped, pass, user, B) * LP + c];
   }
 }
 

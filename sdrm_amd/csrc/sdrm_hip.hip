@@ -18,6 +18,7 @@
 #include "feed.h"
 #include "gemm.h"
 #include "rank.h"
+#include "rowchain.h"
 #include "select.h"
 #include "skinny.h"
 #include "skinny_train.h"
@@ -53,6 +54,8 @@ struct Tuning {
   int wgrad_round = 1280;        // SDRM_WGRAD_ROUND: ... unless ONE round (this many work-groups) already gives eight slices or more
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
   int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
+  int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
+                                 // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
 };
 
 struct sdrm_engine {
@@ -66,6 +69,9 @@ struct sdrm_engine {
   // padded compute copies
   float *W0c = nullptr, *b0c = nullptr, *Whc = nullptr, *bhc = nullptr, *Woc = nullptr, *boc = nullptr;
   float *WhcT = nullptr, *WocT = nullptr;   // transposed copies [in][out]: dgrad is then an NT GEMM like the forwards
+  float *W0f = nullptr, *Whf = nullptr, *Wof = nullptr;   // fragment-packed copies [WP/16][WP/16][64][4] for the row-owned forward
+                                                          // (layer 0: the latent columns only); null when the net does not qualify
+  bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
   float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
@@ -407,21 +413,25 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
     j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
     j.inner = inner;
     j.dstT = dstT; j.dstT_ld = dstT_ld;
+    j.dstF = nullptr; j.dstFT = nullptr; j.fnct = e->WP / 16;
     j.gdst = gbase + off; j.g_ld = flat_ld;
   };
   // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
   add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
   add(e->off_w0, W, L + T, L + T, L, e->slab0, e->K0, (size_t)e->WP * e->K0, S0, e->W0c, e->K0);
+  tab.j[n - 1].dstF = e->W0f;
   add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
   // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
   add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
   if (H >= 1) {
     add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
+    tab.j[n - 1].dstF = e->Whf;
     add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
     add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
         dgrad_blocks);
   }
   add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
+  tab.j[n - 1].dstF = e->Wof;
   add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
   tab.n_adam = n;
   // finalize-only job: the one-hot columns of the layer-0 slabs -> dense dC0T[W][TP] for the emb backward
@@ -468,6 +478,51 @@ int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
 }
 
 bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && e->WP <= 64; }
+
+// Row-owned train forward (rowchain.h): one 96-row work-group per CU.  It replaces staging + H + 2 GEMM launches + the loss
+// partial sums when the batch fills whole rounds of the chip's 256 CUs (measured at B = 8192, L = 340: 169 us against
+// 182 + 18.7 + 11.7 us); a last round that leaves more than a sixth of the CUs idle loses to the per-layer path.
+bool use_rowchain(const sdrm_engine* e, int B) {
+  if (!e->W0f || e->tune.rowchain <= 0 || e->tune.force_cfg >= 0) return false;   // a forced tile means: the per-layer kernels
+  if (e->tune.rowchain >= 2) return true;
+  const int G = (B + RC_USERS - 1) / RC_USERS;
+  const int rounds = (G + 255) / 256;
+  return G >= 216 && G * 6 >= rounds * 256 * 5;
+}
+
+template <int CT>
+int launch_row_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStream_t st) {
+  SDRM_LAUNCH(e, (k_row_fwd<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
+int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd, uint64_t seed,
+                       uint64_t step, float nd, int G, hipStream_t st) {
+  const int n = e->T + 1;
+  RowChainArgs a{};
+  a.x0 = x0;
+  if (mode == SDRM_RNG_EXPLICIT) { a.noise = rnd->noise; a.t = rnd->t; a.keep = rnd->keep; }
+  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n;
+  a.B = B; a.L = e->L; a.T = e->T; a.H = e->H;
+  a.mode = mode; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.step = (uint32_t)step; a.row0 = row0; a.nd = nd;
+  a.W0f = e->W0f; a.Whf = e->Whf; a.Wof = e->Wof; a.bh = e->bhc; a.bo = e->boc; a.B0tab = e->B0tab; a.ldtab = e->WP;
+  a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
+  a.U = e->U; a.K0 = e->K0; a.LPs = e->LP; a.tdev = e->tdev;
+  a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
+  a.loss_part = e->loss_part;
+  switch (e->WP / 32) {
+    case 4: return launch_row_forward_ct<4>(e, a, G, st);
+    case 5: return launch_row_forward_ct<5>(e, a, G, st);
+    case 6: return launch_row_forward_ct<6>(e, a, G, st);
+    case 7: return launch_row_forward_ct<7>(e, a, G, st);
+    case 8: return launch_row_forward_ct<8>(e, a, G, st);
+    case 9: return launch_row_forward_ct<9>(e, a, G, st);
+    case 10: return launch_row_forward_ct<10>(e, a, G, st);
+    case 11: return launch_row_forward_ct<11>(e, a, G, st);
+    default: return fail(e, SDRM_ERR_SHAPE, "row-owned forward: padded width outside 128..352");
+  }
+}
 
 SkinnyTrainArgs skinny_train_args(sdrm_engine* e, int B, int MP) {
   SkinnyTrainArgs a{};
@@ -625,6 +680,16 @@ void reverse_coeffs(const sdrm_engine* e, int i, float& c1, float& sa, float& sb
 // =================================================================================================
 extern "C" {
 
+int sdrm_debug_set_rowchain(sdrm_engine* e, int mode) {
+  if (!e) return SDRM_ERR_ARG;
+  if (e->bwd_begun) return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_rowchain: a two-call backward is in progress");
+  e->fwd_done = false;   // a pending forward's stacked row order belongs to the old setting
+  e->tune.rowchain = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return SDRM_OK;
+}
+
+int sdrm_debug_rowchain_available(const sdrm_engine* e) { return e && e->W0f ? 1 : 0; }
+
 int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
   e->tune.skinny = on ? 1 : 0;
@@ -706,9 +771,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_WGRAD_ROUND")) e->tune.wgrad_round = std::max(1, std::atoi(env));
   if (const char* env = std::getenv("SDRM_AR_BUCKETS")) e->tune.ar_buckets = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
+  if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
-  e->MPmax = round_up(3 * max_rows, 128);
+  e->MPmax = round_up(RC_ROWS * ((max_rows + RC_USERS - 1) / RC_USERS), 128);   // either stacked row order fits
   int64_t o = 0;
   e->off_we = o; o += (int64_t)T * T;
   e->off_be = o; o += T;
@@ -735,6 +801,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->Whc, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
   HIP_TRY(e, dalloc(&e->Woc, (size_t)round_up(e->LP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
   HIP_TRY(e, dalloc(&e->WhcT, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->WocT, (size_t)round_up(e->WP, 128) * e->LP));
+  if (e->LP == e->WP && e->WP >= 128 && e->WP <= 352) {   // the row-owned forward's shape envelope (rowchain.h)
+    HIP_TRY(e, dalloc(&e->W0f, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->Whf, (size_t)e->WP * e->WP));
+    HIP_TRY(e, dalloc(&e->Wof, (size_t)e->WP * e->WP));
+  }
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
@@ -763,7 +833,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   }
   e->alpha_part_stride = std::max(max_gemm_blocks((int)MP, e->WP), (int)MP / 16);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
-  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * LOSS_BLOCKS)); HIP_TRY(e, dalloc(&e->sums, 8));
+  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, MP / RC_ROWS + 1))); HIP_TRY(e, dalloc(&e->sums, 8));
   HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -784,7 +854,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -902,6 +972,23 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     return SDRM_OK;
   }
 
+  e->cur_grouped = false;
+  if (use_rowchain(e, B)) {
+    // row-owned forward (rowchain.h): the step's tables, then staging + every layer + the loss partial sums in ONE launch
+    int rc = emb_tables(e, true, st);
+    if (rc) return rc;
+    const int G = (B + RC_USERS - 1) / RC_USERS, MPg = round_up(G * RC_ROWS, BM);
+    rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st);
+    if (rc) return rc;
+    if (!e->fold_sums) {
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, G, (double)B * (double)e->L,
+                         sums ? sums : e->sums);
+      HIP_TRY(e, hipGetLastError());
+    }
+    e->cur_B = B; e->cur_MP = MPg; e->cur_x0 = x0; e->cur_grouped = true; e->fwd_done = true;
+    return SDRM_OK;
+  }
+
   PrepTrainArgs pa{};
   pa.x0 = x0;
   if (mode == SDRM_RNG_EXPLICIT) { pa.noise = rnd->noise; pa.t = rnd->t; pa.keep = rnd->keep; }
@@ -966,10 +1053,11 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
-  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP;
-  sa.part = e->loss_part; sa.nblk = LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
+  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_grouped ? 1 : 0;
+  sa.part = e->loss_part; sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
   {
-    const unsigned need = (unsigned)(((size_t)(B + (MP - 3 * B)) * (e->LP / 4) + 255) / 256);
+    const int nslots = e->cur_grouped ? RC_USERS * ((B + RC_USERS - 1) / RC_USERS) : B;
+    const unsigned need = (unsigned)(((size_t)(nslots + (MP - 3 * nslots)) * (e->LP / 4) + 255) / 256);
     dim3 grid(std::min(need, 2048u));   // grid-stride beyond: see k_loss_seed
     SDRM_LAUNCH(e, k_loss_seed, grid, dim3(256), 0, st, sa);
     HIP_TRY(e, hipGetLastError());
@@ -1294,7 +1382,7 @@ int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_train_outputs: no forward yet");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
-                     e->LP, psq);
+                     e->LP, e->cur_grouped ? 1 : 0, psq);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }
@@ -1618,7 +1706,7 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
   if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
-                     e->cur_B, e->W, e->WP, out);
+                     e->cur_B, e->W, e->WP, e->cur_grouped ? 1 : 0, out);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }

@@ -73,10 +73,13 @@ class Engine:
         return t.contiguous()
 
     def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None,
-                  gradient_buckets=None):
+                  gradient_buckets=None, rowchain=None):
         """Test / tuning hooks of THIS engine (include/sdrm_hip_debug.h): force a GEMM tile shape (-1 = automatic),
         switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds,
-        the number of gradient all-reduces of the sharded step (1 or 2)."""
+        the number of gradient all-reduces of the sharded step (1 or 2), the row-owned train forward (0 never, 1 by
+        size, 2 whenever the net allows)."""
+        if rowchain is not None:
+            self._check(self.lib.sdrm_debug_set_rowchain(self._h, int(rowchain)), "sdrm_debug_set_rowchain")
         if gradient_buckets is not None:
             self._check(self.lib.sdrm_debug_set_gradient_buckets(self._h, int(gradient_buckets)), "sdrm_debug_set_gradient_buckets")
         if tile is not None:
@@ -92,6 +95,11 @@ class Engine:
                                                           -1 if nt32_rows_train is None else int(nt32_rows_train)),
                         "sdrm_debug_set_nt32_rows")
         return self
+
+    @property
+    def rowchain_available(self):
+        """True when this engine's shape qualifies for the row-owned train forward (csrc/rowchain.h)."""
+        return bool(self.lib.sdrm_debug_rowchain_available(self._h))
 
     # ------------------------------------------------------------------ parameters
     def set_params(self, flat):

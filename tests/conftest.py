@@ -26,3 +26,25 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(scope="module")
+def engine_cls():
+    """The engine class of the GPU tests.  Its debug_set() also takes tile="row": the row-owned train forward
+    (csrc/rowchain.h) forced on with the automatic tile for everything else; the test is skipped when the shape lies
+    outside that kernel's envelope (L == W, padded width 128..352)."""
+    import torch
+
+    from sdrm_amd.engine import Engine
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+
+    class TestEngine(Engine):
+        def debug_set(self, **kw):
+            if kw.get("tile") == "row":
+                if not self.rowchain_available:
+                    self.close()
+                    pytest.skip("shape outside the row-owned forward's envelope")
+                kw = dict(kw, tile=None, rowchain=2)
+            return super().debug_set(**kw)
+
+    return TestEngine

@@ -308,24 +308,29 @@ def reference_loss(ref, net_init, dims, x0, raw_noise, nd, t, masks, schedule):
     return float(loss.detach()), xp.detach().numpy().copy()
 
 
-def fixture_train(ref):
+TRAIN_CASES = [
+    # L,  W,  T, H, batch rows, lr,    nd
+    (24, 24, 9, 2, (5, 3), 2.1e-3, 1.0),
+    (20, 20, 8, 0, (4, 4), 1.0e-3, 0.7),
+    (24, 40, 6, 1, (6, 2), 5.0e-4, 1.0),
+    (40, 40, 93, 5, (7, 5), 1.3e-3, 1.0),
+]
+# a net inside the envelope of the row-owned train forward (csrc/rowchain.h: L == W, padded width 128..352); 37 rows are one
+# full group of 32 users and a partial one, 21 rows a lone partial group
+TRAIN_WIDE_CASES = [(100, 100, 7, 1, (37, 21), 5.0e-4, 0.9)]
+
+
+def fixture_train(ref, cases=TRAIN_CASES, name="train", seed0=0):
     """Whole `train_SDRM()` runs: 2 epochs x 2 batches (short last batch) so the
     per-epoch lr decay (`train_SDRM.py:316`), the shared hidden layer (Q1) and the
     global Adam step counter are all exercised."""
     out = {}
-    cases = [
-        # L,  W,  T, H, batch rows, lr,    nd
-        (24, 24, 9, 2, (5, 3), 2.1e-3, 1.0),
-        (20, 20, 8, 0, (4, 4), 1.0e-3, 0.7),
-        (24, 40, 6, 1, (6, 2), 5.0e-4, 1.0),
-        (40, 40, 93, 5, (7, 5), 1.3e-3, 1.0),
-    ]
     for ci, (L, W, T, H, rows, lr, nd) in enumerate(cases):
-        init = synth.init_params(L, W, T, H, seed=20 + ci)
-        rs = np.random.RandomState(200 + ci)
+        init = synth.init_params(L, W, T, H, seed=20 + ci + seed0)
+        rs = np.random.RandomState(200 + ci + seed0)
         batches = [rs.standard_normal((r, L)).astype(np.float32) for r in rows]
         epochs = 2
-        _, _, tr = run_reference_training(ref, L, W, T, H, batches, epochs, lr, nd, init, seed=300 + ci)
+        _, _, tr = run_reference_training(ref, L, W, T, H, batches, epochs, lr, nd, init, seed=300 + ci + seed0)
         prefix = f"c{ci}_"
         pack_training_trace(prefix, out, tr, batches, epochs, lr, nd, (L, W, T, H), init)
         loss0, xpert0 = reference_loss(ref, init, (L, W, T, H), batches[0], tr["normal"][0], nd,
@@ -334,7 +339,11 @@ def fixture_train(ref):
         out[prefix + "s0_xpert"] = xpert0
         out[prefix + "adam_kw"] = np.asarray([tr["adam_kw"]["lr"], tr["adam_kw"]["weight_decay"], tr["adam_kw"]["eps"]])
     out["n_cases"] = np.asarray(len(cases))
-    np.savez_compressed(os.path.join(HERE, "train.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+
+
+def fixture_train_wide(ref):
+    fixture_train(ref, cases=TRAIN_WIDE_CASES, name="train_wide", seed0=50)
 
 
 def fixture_elementwise(ref):
@@ -633,13 +642,13 @@ def fixture_vae_decode(ref):
 def main():
     torch.set_num_threads(8)
     ref = load_reference()
-    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "elementwise", "sampling", "fullsize", "host", "equal_sparsity", "rank_metrics", "vae_decode"]
+    which = sys.argv[1:] or ["schedule", "temb", "forward", "train", "train_wide", "elementwise", "sampling", "fullsize", "host", "equal_sparsity", "rank_metrics", "vae_decode"]
     if which == ["equal_sparsity"]:     # numpy only: no need to import the reference
         fixture_equal_sparsity()
         print("wrote equal_sparsity")
         return
     table = {"schedule": fixture_schedule, "temb": fixture_timestep_embedding, "forward": fixture_forward,
-             "train": fixture_train, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
+             "train": fixture_train, "train_wide": fixture_train_wide, "elementwise": fixture_elementwise, "sampling": fixture_sampling,
              "fullsize": fixture_fullsize, "host": fixture_host, "ml100k": fixture_ml100k, "e2e": fixture_e2e,
              "equal_sparsity": fixture_equal_sparsity, "rank_metrics": fixture_rank_metrics, "vae_decode": fixture_vae_decode}
     for w in which:

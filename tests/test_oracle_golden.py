@@ -74,11 +74,12 @@ def test_elementwise(golden):
     np.testing.assert_allclose(got.numpy(), g["rev_tensor_4"], rtol=2e-6, atol=1e-6)
 
 
-def test_train_runs(golden):
+@pytest.mark.parametrize("fixture", ["train", "train_wide"])
+def test_train_runs(golden, fixture):
     """Whole reference `train_SDRM()` runs replayed step by step: P/S/Q, loss,
     every gradient (shared-layer accumulation), post-Adam parameters across the
     epoch boundary, final Adam moments."""
-    g = golden("train")
+    g = golden(fixture)
     for ci in range(int(g["n_cases"])):
         pf = f"c{ci}_"
         L, W, T, H = (int(v) for v in g[pf + "dims"])
@@ -117,9 +118,10 @@ def test_train_runs(golden):
         assert (wd, eps_) == (orc.ADAM_WD, orc.ADAM_EPS)
 
 
-def test_train_free_running(golden):
+@pytest.mark.parametrize("fixture", ["train", "train_wide"])
+def test_train_free_running(golden, fixture):
     """No re-synchronisation: 4 consecutive steps must still land on the reference."""
-    g = golden("train")
+    g = golden(fixture)
     for ci in range(int(g["n_cases"])):
         pf = f"c{ci}_"
         L, W, T, H = (int(v) for v in g[pf + "dims"])

@@ -16,13 +16,6 @@ from sdrm_amd import _lib, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine_cls():
-    from sdrm_amd.engine import Engine
-    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
-    return Engine
-
-
 @pytest.mark.parametrize("buckets", [1, 2])
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 1024), (40, 40, 93, 5, 107), (96, 72, 10, 0, 33)])
 def test_one_rank_rccl_step_equals_train_step(engine_cls, dims, buckets):
