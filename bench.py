@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoising-steps/sec (train + sample) on ML-1M-shaped latents.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts its N ranks itself, sdrm_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -315,21 +315,43 @@ def main():
                          "the collectives under the bench protocol, no link time - a projection aid, never the headline number")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: put every rank on cuda:0 (a 1-GPU box), implies a non-RCCL backend")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="tests only (tests/test_bench_launch.py): run the whole protocol - self-launch, rendezvous, windows, MAX over "
+                         "ranks, the JSON line - on the CPU over gloo with tests/bench_stub.py in place of the engine; measures nothing")
+    ap.add_argument("--comm-init-timeout", type=float, default=180.0,
+                    help="N > 1: seconds a rank may spend creating its RCCL communicator before the run exits non-zero instead of hanging")
     args = ap.parse_args()
+
+    # Started as a plain command with --gpus N > 1: this process has not touched the GPU yet - start the N ranks as a child
+    # launcher (sdrm_amd/launch.py), relay rank 0's line (the children inherit stdout) and its exit code.
+    from sdrm_amd import launch
+    if args.gpus > 1 and not launch.inside_launcher():
+        sys.exit(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(0 if args.share_gpu else local_rank)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    stub = args.stub_engine
+    if stub and os.environ.get("SDRM_BENCH_TEST_FAIL_RANK") == str(rank):
+        raise SystemExit(f"bench.py: rank {rank} asked to fail (test hook of tests/test_bench_launch.py)")
+    if stub:
+        args.backend, args.exchange, args.no_cpu_baseline, args.no_other_configs = "gloo", "torch", True, True
+    dev = "cpu" if stub else "cuda"
+    device_sync = (lambda: None) if stub else torch.cuda.synchronize
+    if not stub:
+        torch.cuda.set_device(0 if args.share_gpu else local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
-    from sdrm_amd.engine import Engine
+    if stub:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from bench_stub import StubEngine as Engine
+    else:
+        from sdrm_amd.engine import Engine
     from sdrm_amd.parallel import RcclTrainer, ShardedTrainer, shard_rows
 
     wl = WL
@@ -342,26 +364,40 @@ def main():
         srow0, n_local = shard_rows(n, 0, args.rehearse_shard)
     eng = Engine(L, W, T, H, max_rows=max(rows, n_local))
     eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
-    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)[row0:row0 + rows]).cuda()
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)[row0:row0 + rows]).to(dev)
     # N > 1 over RCCL: the exchange is issued by the library itself (sdrm_train_step_sharded); --exchange torch keeps the
     # torch.distributed collectives between the three phases (the only form a gloo rehearsal can run)
     use_abi = world > 1 and args.exchange == "rccl-abi" and args.backend == "nccl"
     trainer, exchange_used = None, ("none" if world == 1 else "torch.distributed between the phases")
     if use_abi:
-        # every rank must end up on the same exchange: a rank whose communicator could not be made takes all of them to the
-        # torch.distributed form (the line says so) rather than leaving the N-GPU run without a number
+        # Every rank must end up on the same exchange, and ncclCommInitRank is collective: a rank that fails BEFORE it would
+        # leave its peers blocked inside it.  So the ranks agree first, over the torch process group, on what each can check
+        # locally (librccl resolves, the engine sits on this rank's device); only then do all of them create the communicator,
+        # or none.  A watchdog turns a communicator that never comes up into a non-zero exit instead of a hang.
         why = ""
         try:
-            trainer = RcclTrainer(eng, rank, world)
+            local_ok = bool(Engine.comm_available()) and torch.cuda.current_device() == (0 if args.share_gpu else local_rank)
+            if not local_ok:
+                why = "librccl could not be loaded" if not Engine.comm_available() else "engine not on this rank's device"
         except Exception as ex:
-            why = f"{type(ex).__name__}: {ex}"
-        ok = torch.tensor([1 if trainer is not None else 0], dtype=torch.int32, device="cuda")
+            local_ok, why = False, f"{type(ex).__name__}: {ex}"
+        ok = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.cpu()) == 1:
+            import threading
+
+            def give_up():
+                print(f"bench.py: rank {rank}: the RCCL communicator did not come up within {args.comm_init_timeout:.0f} s", file=sys.stderr)
+                os._exit(3)
+
+            watchdog = threading.Timer(args.comm_init_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+            trainer = RcclTrainer(eng, rank, world)   # an exception here ends this rank non-zero; its peers' watchdogs end them
+            watchdog.cancel()
             exchange_used = "RCCL inside libsdrm_hip.so (sdrm_train_step_sharded)"
         else:
-            trainer = None
-            exchange_used = "torch.distributed between the phases (sdrm_comm_init_rank failed on a rank" + (": " + why if why else "") + ")"
+            exchange_used = "torch.distributed between the phases (a rank cannot use the in-library exchange" + (": " + why if why else "") + ")"
             print("bench.py: " + exchange_used, file=sys.stderr)
     if trainer is None and world == 1 and args.rehearse_exchange:
         trainer = RcclTrainer(eng, 0, 1)
@@ -372,13 +408,13 @@ def main():
     job = Job(eng, trainer, x0, row0, n_local, srow0, wl)
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             if args.backend == "nccl":
                 dist.barrier(device_ids=[torch.cuda.current_device()])
             else:
                 dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     # ---- pre-heat: one whole job cycle whatever --warmup says (a 5-step warm-up leaves the first timed train steps
     # cold: round 1's driver line read 20 % under the warm numbers), then the caller's warm-up steps
@@ -401,7 +437,7 @@ def main():
             n_tr += job.step() == "train"
         barrier()
         dt_w = time.perf_counter() - t0
-        tmax = torch.tensor([dt_w], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt_w], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         window_ms.append(float(tmax.cpu()) * 1e3)
@@ -451,6 +487,15 @@ def main():
     eng.sample_begin(n_local, nd=wl["nd"], seed=5, call_id=777, row0=srow0)
     sample_rate = rate(lambda: eng.sample_steps(1), 60)
 
+    # what every rank ran on: its device, its rows, the communicator it sees (a SCALE record then shows that RCCL saw N ranks)
+    comm_n, comm_r = eng.comm_info()
+    mine = {"rank": rank, "device": None if stub else torch.cuda.current_device(), "train_rows": rows, "sample_rows": n_local,
+            "comm_nranks": comm_n, "comm_rank": comm_r, "gradient_buckets": int(getattr(trainer, "buckets", 1))}
+    rank_info = [mine]
+    if world > 1:
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
+
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else None
         roof = None
@@ -491,8 +536,9 @@ def main():
                        "timed_train_steps": round(kinds["train"], 3), "timed_sample_steps": round(kinds["sample"], 3),
                        "rng": "philox4x32-10 on device", "parallelism": f"user-sharded dp{world}",
                        "collectives": ((exchange_used + f" [{args.backend}]"
-                                        + ": all-reduce of 5 f64 loss sums + flat f32 gradient in two buckets per train step")
+                                        + f": all-reduce of 5 f64 loss sums + flat f32 gradient in {mine['gradient_buckets']} bucket(s) per train step")
                                        if (world > 1 or args.rehearse_exchange) else "none")},
+            "exchange_used": exchange_used, "ranks": rank_info,
             "whole_job_tflops": round(job_flops / dt / 1e12, 2),
             "train_steps_per_s": round(train_rate, 2), "sample_steps_per_s": round(sample_rate, 2),
             "launches_per_step": round(launches_total / prof_steps, 2),

@@ -144,6 +144,9 @@ int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, 
  * aux_stream: a hipStream_t for the overlapped bucket (NULL = the library creates one). */
 enum { SDRM_COMM_ID_BYTES = 128 };
 int sdrm_comm_unique_id(void* id_host);
+/* 1 when librccl can be resolved in this process (what sdrm_comm_unique_id / sdrm_comm_init_rank need), else 0: a purely local
+ * check, so that the ranks of a job can agree on the exchange BEFORE any of them enters the collective ncclCommInitRank. */
+int sdrm_comm_available(void);
 int sdrm_comm_init_rank(sdrm_engine* e, int nranks, int rank, const void* id_host);
 int sdrm_allreduce_init(sdrm_engine* e, void* rccl_comm, void* aux_stream);
 int sdrm_comm_info(const sdrm_engine* e, int* nranks, int* rank);   /* nranks 0 / rank -1: no communicator */

@@ -62,21 +62,41 @@ def is_stale() -> bool:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compiles the library when it is missing or stale (or `force`).  Safe against concurrent callers - the ranks of a
+    multi-process run that all find a stale binary: one file lock around the build, the staleness re-checked once the lock is
+    held (the rank that waited finds the fresh binary and compiles nothing), a temp file of its own per process, and an atomic
+    rename, so no process ever loads a half-written file."""
     if not force and not is_stale():
         return LIB_PATH
-    digest = source_hash()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", f'-DSDRM_SOURCE_HASH="{digest}"', "-o", LIB_PATH + ".tmp"]
-    cmd += [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-ldl"]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
-    if verbose and (res.stdout or res.stderr):
-        print(res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    if binary_hash() != digest:
-        raise RuntimeError("libsdrm_hip.so was built but does not carry its source hash")
-    return LIB_PATH
+    import fcntl
+    import tempfile
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB_PATH
+            digest = source_hash()
+            fd, tmp = tempfile.mkstemp(prefix="libsdrm_hip.", suffix=f".{os.getpid()}.tmp", dir=HERE)
+            os.close(fd)
+            try:
+                cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+                       "-Wno-unused-function", f'-DSDRM_SOURCE_HASH="{digest}"', "-o", tmp]
+                cmd += [os.path.join(SRC_DIR, s) for s in SOURCES] + ["-ldl"]
+                res = subprocess.run(cmd, capture_output=True, text=True)
+                if res.returncode != 0:
+                    raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+                if verbose and (res.stdout or res.stderr):
+                    print(res.stdout + res.stderr)
+                os.chmod(tmp, 0o755)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.unlink(tmp)
+            if binary_hash() != digest:
+                raise RuntimeError("libsdrm_hip.so was built but does not carry its source hash")
+            return LIB_PATH
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,7 @@ SIGNATURES = {
     "sdrm_train_step": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, C.POINTER(TrainRandoms), c_uint64, c_uint64,
                                 c_float, c_void_p, c_void_p]),
     "sdrm_comm_unique_id": (c_int, [c_void_p]),
+    "sdrm_comm_available": (c_int, []),
     "sdrm_comm_init_rank": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "sdrm_allreduce_init": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sdrm_comm_info": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int)]),
@@ -117,9 +118,15 @@ def load(build_if_missing: bool = True):
     override = os.environ.get("SDRM_LIB")   # diagnostics only (tools/ab_bench.sh): another build of the same ABI, loaded as it is
     if override:
         lib = C.CDLL(os.path.abspath(override))
+        missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+        if missing:   # another ABI than include/sdrm_hip.h: refuse rather than call through mismatched signatures
+            raise RuntimeError(f"SDRM_LIB={override}: not this ABI, missing {', '.join(missing[:6])}{' ...' if len(missing) > 6 else ''}")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
+        import sys
+        print(f"sdrm_amd: SDRM_LIB override {override} (sources {lib.sdrm_source_hash().decode()[:16]}; in-tree sources "
+              f"{_build.source_hash()[:16]})", file=sys.stderr)
         _LIB = lib
         return lib
     if _build.is_stale():

@@ -226,6 +226,19 @@ __device__ __forceinline__ void store_tile_km(float* __restrict__ dst, const flo
 __host__ __device__ __forceinline__ uint32_t gemm_magic(int d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / (uint32_t)d) + 1u; }
 __device__ __forceinline__ int div_magic(int n, uint32_t m) { return m ? (int)__umulhi((uint32_t)n, m) : n; }
 
+// The grid bookkeeping of a launch in ONE place, so that no caller can set a tile count without its magic: tiles along N, tiles
+// in all, K-slices and the two magics.  The magic division n / d is exact only while n * d < 2^32 - n ranges over the
+// tiles (d = tiles_n) and over slices x tiles (d = nblocks) - so a grid beyond that is refused (false) instead of
+// letting work-groups silently compute wrong tiles.
+__host__ inline bool gemm_set_grid(GemmArgs& a, int tiles_m, int tiles_n, int splits) {
+  if (tiles_m < 1 || tiles_n < 1 || splits < 1) return false;
+  const uint64_t nb = (uint64_t)tiles_m * (uint64_t)tiles_n;
+  if (nb >= (1ull << 31) || nb * (uint64_t)tiles_n >= (1ull << 32) || nb * nb * (uint64_t)splits >= (1ull << 32)) return false;
+  a.tiles_n = tiles_n; a.nblocks = (int)nb; a.nsplits = splits;
+  a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
+  return true;
+}
+
 __device__ __forceinline__ int xcd_remap(int id, int n) {
   const int q = n >> 3, r = n & 7, x = id & 7, s = id >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;

@@ -242,10 +242,7 @@ int max_gemm_blocks(int M, int N) {
 template <class Cfg, int LA, int LB, int XA, int XB, int EPI>
 hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr) {
   const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
-  a.tiles_n = tiles_n;
-  a.nblocks = tiles_m * tiles_n;
-  a.nsplits = splits;
-  a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
+  if (!gemm_set_grid(a, tiles_m, tiles_n, splits)) return hipErrorInvalidValue;   // beyond the exact range of the magic divisions
   dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * splits) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
   const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == pr.cls);
@@ -339,8 +336,7 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     a.slab_stride = (size_t)w[k].Nout * w[k].Kin;
     a.dbias = w[k].dbias; a.dbias_stride = w[k].Nout;
     const int tiles_m = (w[k].Nout + Cfg0::BM - 1) / Cfg0::BM, tiles_n = (w[k].Kin + Cfg0::BN - 1) / Cfg0::BN;
-    a.tiles_n = tiles_n; a.nblocks = tiles_m * tiles_n; a.nsplits = w[k].S;
-    a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);
+    if (!gemm_set_grid(a, tiles_m, tiles_n, w[k].S)) return hipErrorInvalidValue;
     b.start[k] = grid;
 #ifdef SDRM_STAMPS
     a.stamps = (g_wgrad_stamps && g_stamp_class < 0) ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;
@@ -1014,7 +1010,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab; a.ldtab = e->WP; a.trow = e->tdev; a.trow_B = B;
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_ROWTAB>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
-                                                       Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * (e->L + e->T)}, cfg)));
+                                                       Prof{e, PC_FWD_L0, 2.0 * 3 * B * (double)e->W * e->L}, cfg)));   // K = the latents: the time-embedding term is a table row
   }
   int rc = hidden_forward(e, MP, 3 * B, st, cfg);
   if (rc) return rc;
@@ -1255,6 +1251,8 @@ int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, 
       return SDRM_ERR_RCCL;                                                                     \
     }                                                                                           \
   } while (0)
+
+int sdrm_comm_available(void) { return rccl_api(nullptr) != nullptr ? 1 : 0; }
 
 int sdrm_comm_unique_id(void* id_host) {
   if (!id_host) return SDRM_ERR_ARG;
@@ -1625,7 +1623,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
         GemmArgs a{};
         a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = nv.B0tab + (size_t)i * e->WP; a.slopeE = nv.slope0;
         HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, e->Us + (size_t)s0 * e->LP, e->LP, nv.W0c, e->K0, MP, e->WP, e->LP, sc,
-                                                          Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * (e->L + e->T)}, cfg)));
+                                                          Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * e->L}, cfg)));
       }
       int rc = hidden_forward(e, MP, rows, sc, cfg, s0, PC_SMP_HIDDEN, true, &nv);
       if (rc) return rc;
@@ -1803,7 +1801,7 @@ int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, i
     GemmArgs a{};
     a.C = e->dec_buf[HID]; a.ldc = Hp; a.bias = e->dec_buf[B1];
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, e->dec_buf[Z], Lp, e->dec_buf[W1], Lp, rows64, Hp, Lp, st,
-                                                     Prof{e, PC_FWD_L0, 2.0 * n * (double)d->hidden * d->latent}, cfg)));
+                                                     Prof{nullptr, 0, 0.0}, cfg)));
   }
   GemmArgs a{};
   a.C = out; a.ldc = d->n_items; a.bias = e->dec_buf[B2];

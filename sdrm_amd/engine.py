@@ -5,6 +5,7 @@ libsdrm_hip.so.  Reference lines are into /root/reference/train_SDRM.py."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -46,6 +47,7 @@ class Engine:
         assert self.P == synth.param_count(self.L, self.W, self.T, self.H)
         self._sums = torch.zeros(8, dtype=torch.float64, device=self.device)
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.gradient_buckets = 2 if os.environ.get("SDRM_AR_BUCKETS", "1").strip() == "2" else 1   # of train_step_sharded
         self._keepalive = None
 
     # ------------------------------------------------------------------ plumbing
@@ -82,6 +84,7 @@ class Engine:
             self._check(self.lib.sdrm_debug_set_rowchain(self._h, int(rowchain)), "sdrm_debug_set_rowchain")
         if gradient_buckets is not None:
             self._check(self.lib.sdrm_debug_set_gradient_buckets(self._h, int(gradient_buckets)), "sdrm_debug_set_gradient_buckets")
+            self.gradient_buckets = int(gradient_buckets)
         if tile is not None:
             self._check(self.lib.sdrm_debug_set_tile(self._h, int(tile)), "sdrm_debug_set_tile")
         if skinny is not None:
@@ -220,6 +223,11 @@ class Engine:
         return self._loss
 
     # ------------------------------------------------------------------ multi-GPU exchange inside the library
+    @staticmethod
+    def comm_available() -> bool:
+        """True when librccl resolves in this process (a local check: agree on it across ranks BEFORE comm_init_rank)."""
+        return bool(_lib.load().sdrm_comm_available())
+
     @staticmethod
     def comm_unique_id() -> bytes:
         """128-byte RCCL unique id (rank 0 calls this and ships the bytes to the other ranks by any channel)."""

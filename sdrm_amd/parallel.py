@@ -40,6 +40,7 @@ def shard_rows(n_rows: int, rank: int, world: int):
 class ShardedTrainer:
     def __init__(self, engine, rank: int = 0, world: int = 1, group=None, device=None, n_params=None, overlap=False):
         self.engine, self.rank, self.world, self.group, self.overlap = engine, rank, world, group, overlap
+        self.buckets = 2 if overlap else 1
         dev = device if device is not None else getattr(engine, "device", "cpu")
         P = n_params if n_params is not None else engine.P
         self.sums = torch.zeros(8, dtype=torch.float64, device=dev)
@@ -82,6 +83,7 @@ class RcclTrainer:
 
     def __init__(self, engine, rank: int = 0, world: int = 1, unique_id: bytes | None = None, group=None):
         self.engine, self.rank, self.world = engine, rank, world
+        self.buckets = int(getattr(engine, "gradient_buckets", 1))   # what sdrm_train_step_sharded will do (1 unless set otherwise)
         if unique_id is None:
             box = [None]
             if rank == 0:

@@ -190,3 +190,24 @@ def test_shard_rows_partition():
         for (a, la), (b, _) in zip(spans, spans[1:]):
             assert a + la == b
         assert max(s[1] for s in spans) - min(s[1] for s in spans) <= 1
+
+
+def test_tile_coordinate_magic_is_exact_inside_its_range():
+    """csrc/gemm.h takes a work-group's tile coordinates from n / d = umulhi(n, floor(2^32 / d) + 1): exact while n * d < 2^32,
+    the bound gemm_set_grid() enforces on every launch (tiles x tiles_n, and slices x tiles^2 for the split-K unit index)."""
+    rng = np.random.RandomState(0)
+
+    def magic(d):
+        return 0 if d <= 1 else ((1 << 32) // d + 1) & 0xFFFFFFFF
+
+    def div(n, m):
+        return (n * m) >> 32 if m else n
+
+    for d in list(range(1, 70)) + [114, 1352, 4096, 65535, 65536, 92681]:
+        m = magic(d)
+        top = ((1 << 32) - 1) // d          # largest n with n * d < 2^32
+        ns = np.unique(np.concatenate([np.arange(0, min(top, 4096) + 1), rng.randint(0, top + 1, 4096), [top, max(top - 1, 0)]]))
+        for n in ns.tolist():
+            assert div(n, m) == n // d, (n, d)
+    # just past the bound the quotient can be one too large: that is why the launch helpers refuse such grids
+    assert any(div(n, magic(d)) != n // d for d in (3, 7, 11) for n in range(((1 << 32)) // d * d - 1, (1 << 32), 1) if n < (1 << 32))

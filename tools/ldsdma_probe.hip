@@ -183,8 +183,8 @@ void run_case(const Case& c, int reps, int rounds) {
   const int tiles_m = (c.M + 63) / 64, tiles_n = (c.N + 63) / 64, nblocks = tiles_m * tiles_n;
   GemmArgs a{};
   a.A = dA; a.lda = c.K; a.limA = c.M; a.B = dB; a.ldb = c.K; a.limB = c.N; a.C = dC0; a.ldc = Np; a.K = c.K; a.kchunk = c.K;
-  a.tiles_n = tiles_n; a.nblocks = nblocks; a.nsplits = 1; a.slopeA = dSlope;
-  a.magic_tiles_n = gemm_magic(a.tiles_n); a.magic_nblocks = gemm_magic(a.nblocks);   // gemm_body takes its tile coordinates from these
+  a.slopeA = dSlope;
+  if (!gemm_set_grid(a, tiles_m, tiles_n, 1)) { fprintf(stderr, "grid too large\n"); exit(1); }   // tiles, K-slices and the magics gemm_body divides by
   auto launch = [&](int which) {
     switch (which) {
       case 0: hipLaunchKernelGGL((gemm_kernel<Cfg0, LD_KCONTIG, LD_KCONTIG, XFA, XF_NONE, EPI_PLAIN>), dim3(nblocks), dim3(256), 0, 0, a); break;

@@ -119,8 +119,7 @@ int main(int argc, char** argv) {
       ga.C = l < 2 ? dpre + (size_t)l * MP * NP : dY; ga.ldc = NP; ga.K = NP; ga.kchunk = NP;
       ga.bias = l == 2 ? dbo : dbh; ga.slopeA = l == 1 ? dsl : dsl + 1;
       const int tiles_m = (MP + 63) / 64, tiles_n = (NP + 63) / 64;
-      ga.tiles_n = tiles_n; ga.nblocks = tiles_m * tiles_n; ga.nsplits = 1;
-      ga.magic_tiles_n = gemm_magic(ga.tiles_n); ga.magic_nblocks = gemm_magic(ga.nblocks);
+      if (!gemm_set_grid(ga, tiles_m, tiles_n, 1)) { fprintf(stderr, "grid too large\n"); exit(1); }
       ga.rows_valid = MP; ga.cols_valid = NP;
       if (l == 0) hipLaunchKernelGGL((gemm_kernel<Cfg0, LD_KCONTIG, LD_KCONTIG, XF_NONE, XF_NONE, EPI_BIAS>), dim3(ga.nblocks), dim3(256), 0, 0, ga);
       else if (l == 1) hipLaunchKernelGGL((gemm_kernel<Cfg0, LD_KCONTIG, LD_KCONTIG, XF_PRELU, XF_NONE, EPI_BIAS>), dim3(ga.nblocks), dim3(256), 0, 0, ga);
