@@ -59,6 +59,7 @@ struct RowChainArgs {
   // outputs, grouped stacked rows
   float* U; int K0, LPs; int* tdev;
   float* pre; size_t pre_stride; int ldp;   // pre[k] = pre + k * pre_stride, [MP][ldp]
+  float* act;                               // activations prelu(pre[k]) in the same layout (null: not stored)
   float* Y; int ldy;
   double* loss_part;                        // [gridDim.x][4]
   unsigned long long* stamps;               // diagnostic builds only (-DRC_STAMPS): 16 s_memtime slots per work-group
@@ -153,12 +154,16 @@ struct RcSweep {
 // branch inside it, or a load the compiler is free to hoist (loads of read-only memory are not ordered against sched_barrier),
 // and all pieces end up in front of the MFMAs.  Hence compile-time piece counts, and every load's offset is passed through an
 // empty asm volatile at its slot, which pins it there.
-template <int CT, int LDA, int NS>
+// ACT: the streamed tile holds pre-activations and their ACTIVATIONS go to `adst` as well (same offsets): the weight gradients
+// then read their operand as it is - PReLU on operand load costs the split-K kernel a tenth of its time, here it is 12 VALU
+// instructions per chunk.
+template <int CT, int LDA, int NS, bool ACT>
 __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], const f32x4 (&bc)[CT], f32x4 (&an)[3],
                                          f32x4 (&bn)[CT], const gchar* wnext, uint32_t lane16, uint32_t anext, float slope,
-                                         const float* __restrict__ Act, gchar* sdst, RcSweep<8 * CT, LDA>& sw) {
+                                         const float* __restrict__ Act, gchar* sdst, gchar* adst, RcSweep<8 * CT, LDA>& sw) {
   constexpr int NSLOT = 12 * CT;
-  constexpr int P_A = CT, P_S = CT + 3, P_X = P_S + 2 * NS, NPIECE = P_X + 1;
+  constexpr int NPH = ACT ? 3 : 2;   // phases of a chunk: LDS read, store, (activation store)
+  constexpr int P_A = CT, P_S = CT + 3, P_X = P_S + NPH * NS, NPIECE = P_X + 1;
   constexpr int STRIDE = NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1;
   static_assert(NPIECE <= NSLOT && NS <= 2, "not enough MFMA slots for the pipeline pieces");
   float4 sv0 = make_float4(0.f, 0.f, 0.f, 0.f), sv1 = sv0;
@@ -198,8 +203,10 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
             v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Act) + lo);
             so = sw.g_off;
             sw.next();
-          } else {
+          } else if (ph == 1) {
             gstore4(sdst, so, v);
+          } else {
+            gstore4(adst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
           }
         }
       } else {
@@ -387,13 +394,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     }
     // the tile stream: 3 CT chunks over the CT pairs of K-steps (two chunks, then one)
     gchar* sdw = uniform_gptr(sdst);
+    gchar* adw = uniform_gptr(layer == 0 ? nullptr : a.act + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp);
     RcSweep<QP, LDA> sw;
     sw.init(tid, sld);
-    for (int ks = 0; ks < KS; ks += 2) {
-      const int k2 = ks + 2 < KS ? ks + 2 : ks;   // past the end: a harmless re-read
-      rc_kstep<CT, LDA, 2>(acc, a0, b0, a1, b1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, sw);
-      rc_kstep<CT, LDA, 1>(acc, a1, b1, a0, b0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, sw);
-    }
+    auto kloop = [&](auto act_tag) {
+      constexpr bool ACT = decltype(act_tag)::value;
+      for (int ks = 0; ks < KS; ks += 2) {
+        const int k2 = ks + 2 < KS ? ks + 2 : ks;   // past the end: a harmless re-read
+        rc_kstep<CT, LDA, 2, ACT>(acc, a0, b0, a1, b1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, adw, sw);
+        rc_kstep<CT, LDA, 1, ACT>(acc, a1, b1, a0, b0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, adw, sw);
+      }
+    };
+    if (layer == 0 || a.act == nullptr) kloop(std::false_type{});
+    else kloop(std::true_type{});
     if (layer < 3) RC_STAMP(2 + 3 * layer);
     if (last) break;
 

@@ -72,6 +72,9 @@ struct sdrm_engine {
   float *W0f = nullptr, *Whf = nullptr, *Wof = nullptr;   // fragment-packed copies [WP/16][WP/16][64][4] for the row-owned forward
                                                           // (layer 0: the latent columns only); null when the net does not qualify
   bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
+  float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
+                                     // the weight gradients of that step read their operand without PReLU on load
+  bool cur_act = false;              // the last train_forward stored them
   float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
@@ -322,7 +325,7 @@ struct WgradSpec {
   const float* dC; int lddc, Nout; const float* Act; int ldact, Kin; const float* slopeB; int S, kchunk; float* slab; float* dbias;
 };
 
-hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mrows, hipStream_t st, Prof pr) {
+hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mrows, hipStream_t st, Prof pr, bool plain_b = false) {
   GemmBatch b{};
   b.n = n;
   int grid = 0;
@@ -357,8 +360,13 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     hipError_t st0 = hipEventRecord(e->prof_ev[2 * slot], st);
     if (st0 != hipSuccess) return st0;
   }
-  SDRM_LAUNCH(e, (gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_PRELU, EPI_SLAB>), dim3((unsigned)grid),
-                     dim3(NTHREADS), 0, st, b);
+  // plain_b: every B operand is stored as the kernel needs it (activations written by the row-owned forward): no PReLU on load
+  if (plain_b)
+    SDRM_LAUNCH(e, (gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_NONE, EPI_SLAB>), dim3((unsigned)grid),
+                       dim3(NTHREADS), 0, st, b);
+  else
+    SDRM_LAUNCH(e, (gemm_batch_kernel<Cfg0, LD_MCONTIG, LD_MCONTIG, XF_NONE, XF_PRELU, EPI_SLAB>), dim3((unsigned)grid),
+                       dim3(NTHREADS), 0, st, b);
   hipError_t rc = hipGetLastError();
   if (rec && rc == hipSuccess) rc = hipEventRecord(e->prof_ev[2 * slot + 1], st);
   return rc;
@@ -506,6 +514,7 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
   a.U = e->U; a.K0 = e->K0; a.LPs = e->LP; a.tdev = e->tdev;
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
+  a.act = e->act;
   a.loss_part = e->loss_part;
   switch (e->WP / 32) {
     case 4: return launch_row_forward_ct<4>(e, a, G, st);
@@ -800,6 +809,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (e->LP == e->WP && e->WP >= 128 && e->WP <= 352) {   // the row-owned forward's shape envelope (rowchain.h)
     HIP_TRY(e, dalloc(&e->W0f, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->Whf, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->Wof, (size_t)e->WP * e->WP));
+    HIP_TRY(e, dalloc(&e->act, (size_t)(H + 1) * e->MPmax * e->WP));
   }
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
@@ -850,7 +860,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -968,7 +978,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     return SDRM_OK;
   }
 
-  e->cur_grouped = false;
+  e->cur_grouped = false; e->cur_act = false;
   if (use_rowchain(e, B)) {
     // row-owned forward (rowchain.h): the step's tables, then staging + every layer + the loss partial sums in ONE launch
     int rc = emb_tables(e, true, st);
@@ -981,7 +991,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
                          sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
-    e->cur_B = B; e->cur_MP = MPg; e->cur_x0 = x0; e->cur_grouped = true; e->fwd_done = true;
+    e->cur_B = B; e->cur_MP = MPg; e->cur_x0 = x0; e->cur_grouped = true; e->cur_act = true; e->fwd_done = true;
     return SDRM_OK;
   }
 
@@ -1125,10 +1135,13 @@ int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
     w.push_back(WgradSpec{dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, e->one_dev, e->bwd_S0, e->bwd_kc0, e->slab0, e->db0s});
     fl.push_back(fl0);
   }
-  w.push_back(WgradSpec{e->dY, e->LP, e->LP, pre_buf(e, H), e->WP, e->WP, slope_ptr(e, H), SO, e->bwd_kcO, e->slabO, e->dbOs});
+  // operand of the upper layers' weight gradients: the stored pre-activation (PReLU on load), or the activation itself
+  const bool plain = e->cur_act;
+  auto opnd = [&](int k) { return plain ? e->act + (size_t)k * e->MPmax * e->WP : pre_buf(e, k); };
+  w.push_back(WgradSpec{e->dY, e->LP, e->LP, opnd(H), e->WP, e->WP, slope_ptr(e, H), SO, e->bwd_kcO, e->slabO, e->dbOs});
   fl.push_back(flO);
   for (int k = H; k >= 1; --k) {
-    w.push_back(WgradSpec{dpre_buf(e, k), e->WP, e->WP, pre_buf(e, k - 1), e->WP, e->WP, slope_ptr(e, k - 1), SH, e->bwd_kcH,
+    w.push_back(WgradSpec{dpre_buf(e, k), e->WP, e->WP, opnd(k - 1), e->WP, e->WP, slope_ptr(e, k - 1), SH, e->bwd_kcH,
                           e->slabH + (size_t)(k - 1) * SH * e->WP * e->WP, e->dbHs + (size_t)(k - 1) * SH * e->WP});
     fl.push_back(flH);
   }
@@ -1136,7 +1149,7 @@ int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
     const int n = (int)std::min<size_t>(GEMM_BATCH_MAX, w.size() - lo);
     double f = 0.0;
     for (int k = 0; k < n; ++k) f += fl[lo + k];
-    HIP_TRY(e, launch_wgrad_batch(e, w.data() + lo, n, MP, st, Prof{e, PC_WGRAD, f}));
+    HIP_TRY(e, launch_wgrad_batch(e, w.data() + lo, n, MP, st, Prof{e, PC_WGRAD, f}, plain));
   }
   return SDRM_OK;
 }

@@ -93,6 +93,7 @@ int main(int argc, char** argv) {
   float* dU = dalloc<float>((size_t)MP * K0);
   float* dpre = dalloc<float>((size_t)(H + 1) * MP * NP);
   float* dY = dalloc<float>((size_t)MP * NP);
+  float* dact = dalloc<float>((size_t)(H + 1) * MP * NP);
   int* dtdev = dalloc<int>(B);
   double* dpart = dalloc<double>((size_t)4 * G);
 
@@ -102,7 +103,7 @@ int main(int argc, char** argv) {
   a.W0f = dWf[0]; a.Whf = dWf[1]; a.Wof = dWf[2]; a.bh = dbh; a.bo = dbo; a.B0tab = dB0tab; a.ldtab = NP;
   a.slope0 = dsl; a.slopeh = dsl + 1;
   a.U = dU; a.K0 = K0; a.LPs = NP; a.tdev = dtdev; a.pre = dpre; a.pre_stride = (size_t)MP * NP; a.ldp = NP; a.Y = dY; a.ldy = NP;
-  a.loss_part = dpart;
+  a.loss_part = dpart; a.act = dact;
 
   auto launch_row = [&](int mode) {
     RowChainArgs b = a;
@@ -176,6 +177,18 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // the activation copies: prelu of the GPU's own pre-activations, every element of every group's rows
+  double eA = 0;
+  {
+    std::vector<float> gact((size_t)2 * MP * NP);
+    CHECK(hipMemcpy(gact.data(), dact, gact.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < 2; ++l)
+      for (size_t r = 0; r < (size_t)G * RC_ROWS; ++r)
+        for (int c = 0; c < NP; ++c) {
+          const float p = gpre[(size_t)l * MP * NP + r * NP + c], sl = l == 0 ? slope0 : slopeh;
+          eA = std::max(eA, std::fabs((double)(p > 0.f ? p : sl * p) - (double)gact[(size_t)l * MP * NP + r * NP + c]));
+        }
+  }
   // loss partial sums of every group against the GPU's own Y (fp64 on the host)
   double eS = 0, mS = 0;
   for (int g = 0; g < G; ++g) {
@@ -192,9 +205,10 @@ int main(int argc, char** argv) {
     for (int j = 0; j < 4; ++j) { eS = std::max(eS, std::fabs(s[j] - gpart[4 * (size_t)g + j])); mS = std::max(mS, std::fabs(s[j])); sums_ref[j] += s[j]; }
   }
   printf("# B=%d G=%d work-groups, LDS %zu B per work-group\n", B, G, RowChainCfg<CT>::LDS_BYTES);
+  printf("max|act - prelu(pre)| %.2e\n", eA);
   printf("max|err|: U %.2e  pre0 %.2e (max %.2f)  pre1 %.2e (max %.2f)  Y %.2e (max %.2f)  loss partials %.2e (max %.3e)\n", eU, e0, m0, e1, m1,
          eY, mY, eS, mS);
-  const bool ok = eU < 1e-6 && e0 < 1e-4 * m0 && e1 < 1e-4 * m1 && eY < 1e-4 * mY && eS < 1e-3 * mS;   // float32 partial sums: per-quad f32, then f64
+  const bool ok = eA < 1e-6 && eU < 1e-6 && e0 < 1e-4 * m0 && e1 < 1e-4 * m1 && eY < 1e-4 * mY && eS < 1e-3 * mS;   // float32 partial sums: per-quad f32, then f64
   printf("parity %s\n", ok ? "OK" : "FAILED");
 
 #ifdef RC_STAMPS
