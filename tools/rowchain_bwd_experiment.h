@@ -1,12 +1,21 @@
+// EXPERIMENT, not part of libsdrm_hip.so (tools/rowbwd_probe.hip): the row-owned BACKWARD chain - loss seeds and every dgrad of a
+// 96-row group in one work-group - together with the forward variant it needs (pre-activations handed over in fragment order,
+// single-buffered B fragments).  Parity-green against fp64, but slower than what it would replace: 171 us against 17 + 2 x 60 us
+// for k_loss_seed + the two per-layer dgrad launches at ML-1M, B = 8192 (profiles/r03_row_backward_probe.txt): 132 registers of
+// pre-activations across the K loop spill, the output burst of the last layer costs 33 us, and the forward pays 5.5 k cycles per
+// layer for the fragment-order stores.  Kept for the record; the product's rowchain.h is the forward only.
 // Row-owned train forward for mid-width eps-nets (64 < padded width <= 352, L == W) on gfx950: the north-star's
 // "persistent-threadblock MLP with LDS-resident activations", at TRAIN size.
 //
 // Ownership: ONE work-group per CU owns 96 stacked rows - the P, S and Q rows of 32 users (train_SDRM.py:331-333: the three
 // forwards of a train step) - through staging (q_sample + three dropout masks, :326-331 / :100) and ALL H+2 layers (:97-103).
 //   * the 96 x NP activation tile lives in LDS (135 KB at NP = 352) and is overwritten in place after each layer's barrier;
-//     it holds the layer INPUT as it is stored for the backward (dropped-out latents for layer 0, pre-activations above:
-//     PReLU is applied when a fragment is read), so the same tile is streamed out to HBM - U, pre[k], coalesced 16-byte
-//     stores - a few rows per K-step while the next layer multiplies out of it: no store burst, no separate staging launch;
+//     it holds the layer INPUT (dropped-out latents for layer 0, pre-activations above: PReLU is applied when a fragment is
+//     read), and the same tile is streamed out to HBM as the weight gradients want it - U, then the ACTIVATIONS prelu(pre[k]),
+//     coalesced 16-byte stores - a few rows per K-step while the next layer multiplies out of it: no store burst, no separate
+//     staging launch, no PReLU on operand load in the split-K kernel.  The pre-activations themselves go to HBM from the
+//     accumulators in FRAGMENT order (one 16-byte store per lane and tile): only the row-owned backward reads them, at the same
+//     accumulator positions, with one 16-byte load per lane and tile;
 //   * the weights never touch LDS: every wave fetches its MFMA B fragments straight from L2 out of a FRAGMENT-PACKED copy
 //     ([k-step][column tile][lane][4 floats]: one contiguous 1 KiB wave-load per 16x16 tile and 16-deep K-step; k_adam
 //     writes these copies beside the padded ones), double-buffered in registers one whole K-step (132 MFMAs = 4224 cycles)
@@ -27,10 +36,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "elementwise.h"
-#include "gemm.h"
-#include "philox.h"
-#include "skinny.h"
+#include "../sdrm_amd/csrc/elementwise.h"
+#include "../sdrm_amd/csrc/gemm.h"
+#include "../sdrm_amd/csrc/philox.h"
+#include "../sdrm_amd/csrc/skinny.h"
 
 namespace sdrm {
 
@@ -58,8 +67,8 @@ struct RowChainArgs {
   const float* slope0; const float* slopeh;
   // outputs, grouped stacked rows
   float* U; int K0, LPs; int* tdev;
-  float* pre; size_t pre_stride; int ldp;   // pre[k] = pre + k * pre_stride, [MP][ldp]
-  float* act;                               // activations prelu(pre[k]) in the same layout (null: not stored)
+  float* pre; size_t pre_stride;            // pre-activations pre[k] = pre + k * pre_stride in FRAGMENT order (rc_frag_index)
+  float* act; int ldp;                      // activations prelu(pre[k]) = act + k * pre_stride, row-major [MP][ldp]
   float* Y; int ldy;
   double* loss_part;                        // [gridDim.x][4]
   unsigned long long* stamps;               // diagnostic builds only (-DRC_STAMPS): 16 s_memtime slots per work-group
@@ -154,46 +163,46 @@ struct RcSweep {
 // branch inside it, or a load the compiler is free to hoist (loads of read-only memory are not ordered against sched_barrier),
 // and all pieces end up in front of the MFMAs.  Hence compile-time piece counts, and every load's offset is passed through an
 // empty asm volatile at its slot, which pins it there.
-// ACT: the streamed tile holds pre-activations and their ACTIVATIONS go to `adst` as well (same offsets): the weight gradients
-// then read their operand as it is - PReLU on operand load costs the split-K kernel a tenth of its time, here it is 12 VALU
-// instructions per chunk.
-template <int CT, int LDA, int NS, bool ACT>
-__device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], const f32x4 (&bc)[CT], f32x4 (&an)[3],
-                                         f32x4 (&bn)[CT], const gchar* wnext, uint32_t lane16, uint32_t anext, float slope,
-                                         const float* __restrict__ Act, gchar* sdst, gchar* adst, RcSweep<8 * CT, LDA>& sw) {
-  constexpr int NSLOT = 12 * CT;
-  constexpr int NPH = ACT ? 3 : 2;   // phases of a chunk: LDS read, store, (activation store)
-  constexpr int P_A = CT, P_S = CT + 3, P_X = P_S + NPH * NS, NPIECE = P_X + 1;
-  constexpr int STRIDE = NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1;
-  static_assert(NPIECE <= NSLOT && NS <= 2, "not enough MFMA slots for the pipeline pieces");
+// XF: PReLU on the A fragments as they are read (the forward above layer 0).  SM: what the tile stream stores - 0 the tile as
+// it is (U; gradients in the backward), 1 prelu(tile): the ACTIVATIONS of the pre-activations the tile holds.
+// MFMA order: column tile outermost - a B fragment serves 12 consecutive MFMAs (4 k x 3 row tiles) and its register is
+// refilled for the NEXT K-step right behind them (one buffer instead of two: the backward keeps 132 registers of
+// pre-activations across the loop); an accumulator is revisited every third MFMA (96 cycles, the dependent latency is 40).
+template <int CT, int LDA, int NS, bool XF, int SM>
+__device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], f32x4 (&b)[CT], f32x4 (&an)[3],
+                                         const gchar* wnext, uint32_t lane16, uint32_t anext, float slope,
+                                         const float* __restrict__ Act, gchar* sdst, RcSweep<8 * CT, LDA>& sw) {
+  // pieces besides the B refills: 3 A reads, 2 NS stream phases, the PReLU group; two slots per column-tile block
+  constexpr int NOTHER = 3 + 2 * NS + (XF ? 1 : 0);
+  static_assert(NOTHER <= 2 * CT && NS <= 2, "not enough MFMA slots for the pipeline pieces");
   float4 sv0 = make_float4(0.f, 0.f, 0.f, 0.f), sv1 = sv0;
   uint32_t so0 = 0, so1 = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
-    const int s = (e * CT + ct) * 3 + rt;
-    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][e], bc[ct][e], acc[rt][ct], 0, 0, 0);
-    if (s % STRIDE == 0 && s / STRIDE < NPIECE) {
-      const int p = s / STRIDE;
-      if (p < P_A) {
-        if (!(RC_DIAG & 2)) {
-          // a scalar base per 4 KiB (the immediate offset field covers the rest), opaque at this slot: pins the load here
-          const gchar* wb = wnext + (p / 4) * 4096;
-          asm volatile("" : "+s"(wb));
-          bn[p] = gload4(wb + (p % 4) * 1024, lane16);
-        }
-      } else if (p < P_S) {
+    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][e], b[ct][e], acc[rt][ct], 0, 0, 0);
+    const int w = e * 3 + rt;   // position inside the block of 12
+    if (w == 11) {
+      if (!(RC_DIAG & 2)) {
+        // a scalar base per 4 KiB (the immediate offset field covers the rest), opaque at this slot: pins the load here
+        const gchar* wb = wnext + (ct / 4) * 4096;
+        asm volatile("" : "+s"(wb));
+        b[ct] = gload4(wb + (ct % 4) * 1024, lane16);
+      }
+    } else if (w == 3 || w == 7) {
+      const int p = 2 * ct + (w == 7 ? 1 : 0);
+      if (p < 3) {
         if (!(RC_DIAG & 4)) {
           uint32_t ao = anext;
           asm volatile("" : "+v"(ao));
-          an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
+          an[p] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + p * RC_USERS * LDA * 4);
         }
-      } else if (p < P_X) {
+      } else if (p < 3 + 2 * NS) {
         // tile stream, chunk q: LDS read, then (NS pieces later) the HBM store and the step to the next chunk
-        const int k = p - P_S, ph = k / NS, q = k % NS;
+        const int k = p - 3, ph = k / NS, q = k % NS;
         if (!(RC_DIAG & 1)) {
           float4& v = q == 0 ? sv0 : sv1;
           uint32_t& so = q == 0 ? so0 : so1;
@@ -203,14 +212,14 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
             v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Act) + lo);
             so = sw.g_off;
             sw.next();
-          } else if (ph == 1) {
+          } else if (SM == 0) {
             gstore4(sdst, so, v);
           } else {
-            gstore4(adst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
+            gstore4(sdst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
           }
         }
-      } else {
-        if (!(RC_DIAG & 8)) {
+      } else if (p == 3 + 2 * NS) {
+        if (XF && !(RC_DIAG & 8)) {
 #pragma unroll
           for (int f = 0; f < 3; ++f) {
             an[f].x = prelu_any(an[f].x, slope); an[f].y = prelu_any(an[f].y, slope);
@@ -223,7 +232,20 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
   }
 }
 
-// four doubles summed over the work-group, every thread gets the totals (one barrier pair instead of four)
+// float offset of accumulator tile (rt, ct) of wave `wave` of group g in a fragment-ordered buffer: [g][wave][rt][ct][lane][4]
+template <int CT>
+__host__ __device__ inline size_t rc_frag_tile(int g, int wave, int rt, int ct) {
+  return ((((size_t)g * 4 + wave) * 3 + rt) * CT + ct) * 256;
+}
+// float offset of element (row of the group, column) in that buffer (wave (wr, wc) owns rows 32 rt + 16 wr + 4 lq + r, columns
+// 16 (CT wc + ct) + li; lane = 16 lq + li, component r)
+__host__ __device__ inline size_t rc_frag_index(int CT, int g, int row, int col) {
+  const int rt = row / RC_USERS, wr = (row % RC_USERS) / 16, lq = (row % 16) / 4, r = row % 4;
+  const int wc = col / (16 * CT), ct = (col / 16) % CT, li = col % 16;
+  return (((((size_t)g * 4 + (2 * wr + wc)) * 3 + rt) * CT + ct) * 64 + (size_t)(16 * lq + li)) * 4 + r;
+}
+
+// four doubles summed over the work-group, every thread gets the totals (one barrier pair)
 __device__ __forceinline__ void block_sum4(double (&v)[4], double* sh /* [16] */) {
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -289,15 +311,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   {
     const int tt = trow[su];
     const float sa = a.sqrt_ab[tt], om = a.one_minus_ab[tt];
-    // PHILOX mode: the thread's NQ calls (one per column quad: two normal pairs and, in the low bits of word j, the three keep
-    // bits of column j) in ONE straight-line block - a call is a serial chain of 10 rounds, and with one wave per SIMD nothing
-    // but the other calls of the same thread can fill its latencies
-    U4 rw[NQ];
-    if (a.mode != 0) {
-#pragma unroll
-      for (int j = 0; j < NQ; ++j)
-        rw[j] = philox4x32_10((uint32_t)(a.row0 + susr), (uint32_t)(sq + 8 * j), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo, a.seed_hi);
-    }
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int c = 4 * (sq + 8 * j);
@@ -307,7 +320,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
         float e[4] = {0.f, 0.f, 0.f, 0.f};
         uint32_t bits[4] = {0u, 0u, 0u, 0u};
         if (a.mode != 0) {
-          const U4 w = rw[j];
+          // ONE Philox call per column quad: two normal pairs and, in the low bits of word j, the three keep bits of column j
+          const U4 w = philox4x32_10((uint32_t)(a.row0 + susr), (uint32_t)(c >> 2), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo, a.seed_hi);
           box_muller(w.x, w.y, e[0], e[1]);
           box_muller(w.z, w.w, e[2], e[3]);
 #pragma unroll
@@ -361,7 +375,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   const uint32_t lane16 = 16u * (uint32_t)lane;   // byte offset of a lane's float4 in a 1 KiB wave-load / wave-store
   const int myusr = u0 + 16 * wr + 4 * lq;                      // + r: the user of accumulator register r (every rt, ct)
   f32x4 acc[RT][CT];
-  f32x4 b0[CT], b1[CT];
+  f32x4 b0[CT];   // B fragments of the current K-step, refilled in place for the next one
   f32x4 a0[RT], a1[RT];
   float xq[CT][4];   // x0 at this lane's accumulator positions (loss sums), requested before the out layer's loop
 
@@ -371,8 +385,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     const gchar* Wf = uniform_gptr((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)(CT * wc) * 256);
     // PReLU on fragment read; layer 0's input is not a pre-activation: slope 1 leaves it as it is, bit for bit
     const float slope = layer == 0 ? 1.f : (layer == 1 ? *a.slope0 : *a.slopeh);
-    // this layer streams its own input tile out to HBM while it multiplies: U (layer 0) or pre[layer - 1]
-    float* __restrict__ sdst = layer == 0 ? a.U + grow0 * a.K0 : a.pre + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp;
+    // this layer streams its own input tile out to HBM while it multiplies: U (layer 0), or the activations of pre[layer - 1]
+    float* __restrict__ sdst = layer == 0 ? a.U + grow0 * a.K0 : a.act + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp;
     const int sld = layer == 0 ? a.K0 : a.ldp;
 
     // accumulators start at the bias (layer 0: the row's own row of b0 + C0[t])
@@ -419,18 +433,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     }
     // the tile stream: 3 CT chunks over the CT pairs of K-steps (two chunks, then one)
     gchar* sdw = uniform_gptr(sdst);
-    gchar* adw = uniform_gptr(layer == 0 ? nullptr : a.act + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp);
     RcSweep<QP, LDA> sw;
     sw.init(tid, sld);
-    auto kloop = [&](auto act_tag) {
-      constexpr bool ACT = decltype(act_tag)::value;
+    auto kloop = [&](auto above0) {
+      constexpr bool UP = decltype(above0)::value;   // above layer 0: PReLU on fragment read, activations streamed
       for (int ks = 0; ks < KS; ks += 2) {
         const int k2 = ks + 2 < KS ? ks + 2 : ks;   // past the end: a harmless re-read
-        rc_kstep<CT, LDA, 2, ACT>(acc, a0, b0, a1, b1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, adw, sw);
-        rc_kstep<CT, LDA, 1, ACT>(acc, a1, b1, a0, b0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, adw, sw);
+        rc_kstep<CT, LDA, 2, UP, UP ? 1 : 0>(acc, a0, b0, a1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, sw);
+        rc_kstep<CT, LDA, 1, UP, UP ? 1 : 0>(acc, a1, b0, a0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, sw);
       }
     };
-    if (layer == 0 || a.act == nullptr) kloop(std::false_type{});
+    if (layer == 0) kloop(std::false_type{});
     else kloop(std::true_type{});
     if (layer < 3) RC_STAMP(2 + 3 * layer);
     if (last) break;
@@ -439,12 +452,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     __syncthreads();
     if (layer < 3) RC_STAMP(3 + 3 * layer);
     float* __restrict__ obase = Act + (16 * wr + 4 * lq) * LDA + 16 * CT * wc + li;   // + (32 * rt + r) * LDA + 16 * ct
+    gchar* pfw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + rc_frag_tile<CT>(g, wave, 0, 0));   // fragment order
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+      for (int rt = 0; rt < RT; ++rt) {
+        gstore4(pfw + (rt * CT + ct) * 1024, lane16, make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) obase[(RC_USERS * rt + r) * LDA + 16 * ct] = acc[rt][ct][r];
+      }
     __syncthreads();
     if (layer < 3) RC_STAMP(4 + 3 * layer);
   }
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
       ydst[(size_t)(2 * RC_USERS + r) * a.ldy + 16 * ct] = Q;
       if (myusr + r < a.B && col < a.L) {
         const float R = P - xq[ct][r];
-        const float D = (Q - S) * (1.f / MU2) - R;   // a multiply: an IEEE division is ten instructions, 132 times per lane
+        const float D = (Q - S) / MU2 - R;
         const float RS = R - S;
         fD += D * D; fC += RS * RS; fR += R; fR2 += R * R;
       }
@@ -472,11 +488,205 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     sD += fD; sC += fC; sR += fR; sR2 += fR2;
   }
   RC_STAMP(9);
-  double tot[4] = {sD, sC, sR, sR2};
-  block_sum4(tot, red);
+  const double tD = block_sum(sD, red), tC = block_sum(sC, red), tR = block_sum(sR, red), tR2 = block_sum(sR2, red);
   if (tid == 0) {
     double* o = a.loss_part + 4 * (size_t)g;
-    o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3];
+    o[0] = tD; o[1] = tC; o[2] = tR; o[3] = tR2;
+  }
+#ifdef RC_STAMPS
+  RC_STAMP(10);
+  if (tid == 0 && a.stamps) {
+    st_[12] = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 16; ++i) a.stamps[16 * (size_t)g + i] = st_[i];
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-owned backward chain: loss seeds (score_matching_loss gradients x tanh') and every dgrad of the three
+// stacked passes, same ownership as the forward - a work-group keeps the gradient tile of its 96 rows in LDS from the output
+// down to layer 0.  Per layer: dact = dpre_above * W (B fragments of the TRANSPOSED weight, fragment-packed by k_adam), then
+// dpre = dact * prelu'(pre) with the pre-activations the forward left in fragment order (requested before the K loop, in
+// registers when the loop ends), the slope-gradient partial sum(dact * min(pre, 0)) per work-group, and the tile streamed to
+// HBM row-major for the weight gradients while the next layer multiplies out of it.  Replaces k_loss_seed + H + 1 GEMM launches.
+struct RowBwdArgs {
+  const float* Y; int ldy; const float* x0; int B, L, H, MP;
+  const double* sums;                       // the five global sums (all-reduced), or null: fold part[nblk][4] here
+  const double* part; int nblk; double count;
+  const float* WofT; const float* WhfT;     // fragment-packed transposed weights: B[n = in][k = out]
+  const float* slope0; const float* slopeh;
+  const float* pre; size_t pre_stride;      // fragment order, as k_row_fwd left them
+  float* dY; float* dpre; int ldp;          // row-major [MP][ldy] / dpre[k] = dpre + k * pre_stride, [MP][ldp]
+  float* alpha_part; int alpha_part_stride; // slope partials [application][work-group]
+  float* loss;
+  unsigned long long* stamps;
+};
+
+template <int CT>
+__global__ __launch_bounds__(NTHREADS, 1) void k_row_bwd(const RowBwdArgs a) {
+  typedef RowChainCfg<CT> C;
+  constexpr int NP = C::NP, NCT = C::NCT, KS = C::KS, QP = C::QP, LDA = C::LDA, RT = 3, NQ = QP / 8;
+  __shared__ __attribute__((aligned(16))) float Act[RC_ROWS * LDA];
+  __shared__ double red[16];
+  __shared__ float redf[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lq = lane >> 4;
+  const int g = blockIdx.x, u0 = RC_USERS * g;
+  const size_t grow0 = (size_t)RC_ROWS * g;
+#ifdef RC_STAMPS
+  unsigned long long st_[16] = {0};
+#endif
+  RC_STAMP(0);
+
+  // ---------------------------------------------------------------- the five sums -> seed coefficients (k_loss_seed's arithmetic)
+  double sm[4] = {0, 0, 0, 0}, N;
+  if (a.sums) {
+    sm[0] = a.sums[0]; sm[1] = a.sums[1]; sm[2] = a.sums[2]; sm[3] = a.sums[3]; N = a.sums[4];
+  } else {
+    for (int i = tid; i < a.nblk; i += NTHREADS)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sm[j] += a.part[4 * (size_t)i + j];
+    block_sum4(sm, red);
+    N = a.count;
+  }
+  const double Am = sm[0] / N, Cm = sm[1] / N, Rbar = sm[2] / N;
+  const double V = (N > 1.0) ? (sm[3] - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");   // torch.var of one element: nan (:198)
+  const double den = 1e-8 + V;
+  const float cD = (float)(2.0 * (0.5 / den) / N);
+  const float cV = (float)(-(0.5 * (Am + Cm) / (den * den)) * 2.0 / (N - 1.0));
+  const float rbar = (float)Rbar;
+  if (g == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (Am + Cm) / den);
+
+  // padding rows behind the last group (the weight gradients read whole 64-row tiles): zero, a few stores per work-group
+  {
+    const int tail = a.MP - RC_ROWS * (int)gridDim.x;
+    const int per = tail * QP;                                   // float4 per buffer
+    for (int f = g * NTHREADS + tid; f < per * (a.H + 2); f += (int)gridDim.x * NTHREADS) {
+      const int buf = f / per, q = f - buf * per, row = q / QP, c = 4 * (q - row * QP);
+      float* dst = buf == 0 ? a.dY + ((size_t)RC_ROWS * gridDim.x + row) * a.ldy
+                            : a.dpre + (size_t)(buf - 1) * a.pre_stride + ((size_t)RC_ROWS * gridDim.x + row) * a.ldp;
+      *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  // ---------------------------------------------------------------- seeds: dY tile into LDS, thread -> (user tid >> 3, quads (tid & 7) + 8 j)
+  {
+    const int su = tid >> 3, sq = tid & 7, susr = u0 + su;
+    const float* yP = a.Y + (grow0 + su) * a.ldy;
+    const float* yS = yP + (size_t)RC_USERS * a.ldy;
+    const float* yQ = yS + (size_t)RC_USERS * a.ldy;
+    constexpr int HB = (NQ + 1) / 2;   // two batches of loads (registers)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float4 P4[HB], S4[HB], Q4[HB], X4[HB];
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int jj = h * HB + j, c = 4 * (sq + 8 * jj);
+        const bool on = jj < NQ && susr < a.B && c < a.L;
+        P4[j] = on ? *reinterpret_cast<const float4*>(yP + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        S4[j] = on ? *reinterpret_cast<const float4*>(yS + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        Q4[j] = on ? *reinterpret_cast<const float4*>(yQ + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        X4[j] = on ? load4_unpadded(a.x0, susr, c, a.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int jj = h * HB + j, c = 4 * (sq + 8 * jj);
+        if (jj >= NQ) continue;
+        const float p_[4] = {P4[j].x, P4[j].y, P4[j].z, P4[j].w}, s_[4] = {S4[j].x, S4[j].y, S4[j].z, S4[j].w},
+                    q_[4] = {Q4[j].x, Q4[j].y, Q4[j].z, Q4[j].w}, x_[4] = {X4[j].x, X4[j].y, X4[j].z, X4[j].w};
+        float gP[4] = {0.f, 0.f, 0.f, 0.f}, gS[4] = {0.f, 0.f, 0.f, 0.f}, gQ[4] = {0.f, 0.f, 0.f, 0.f};
+        if (susr < a.B) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (c + k < a.L) {
+              const float P = p_[k], S = s_[k], Q = q_[k];
+              const float R = P - x_[k];
+              const float D = (Q - S) / MU2 - R;
+              const float gD = cD * D, gC = cD * (R - S), gV = cV * (R - rbar);
+              gP[k] = (-gD + gC + gV) * (1.f - P * P);
+              gQ[k] = (gD / MU2) * (1.f - Q * Q);
+              gS[k] = (-gD / MU2 - gC) * (1.f - S * S);
+            }
+          }
+        }
+        *reinterpret_cast<float4*>(Act + su * LDA + c) = make_float4(gP[0], gP[1], gP[2], gP[3]);
+        *reinterpret_cast<float4*>(Act + (RC_USERS + su) * LDA + c) = make_float4(gS[0], gS[1], gS[2], gS[3]);
+        *reinterpret_cast<float4*>(Act + (2 * RC_USERS + su) * LDA + c) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
+      }
+    }
+  }
+  __syncthreads();
+  RC_STAMP(1);
+
+  // ---------------------------------------------------------------- dgrad chain: j = H + 1 (out layer) ... 1
+  const float* abase = Act + (16 * wr + li) * LDA + 4 * lq;
+  const uint32_t aoff = (uint32_t)(((16 * wr + li) * LDA + 4 * lq) * 4);
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  f32x4 acc[RT][CT];
+  f32x4 b0[CT];   // B fragments of the current K-step, refilled in place for the next one
+  f32x4 a0[RT], a1[RT];
+  f32x4 pf[RT][CT];   // pre-activations below this layer at the accumulator positions
+  for (int j = a.H + 1; j >= 1; --j) {
+    const bool first = j == a.H + 1, lastl = j == 1;
+    const gchar* Wf = uniform_gptr((first ? a.WofT : a.WhfT) + (size_t)(CT * wc) * 256);
+    const float slope = j - 1 == 0 ? *a.slope0 : *a.slopeh;   // PReLU between layer j - 1 and layer j
+    // the tile this layer reads goes to HBM meanwhile: dY, or dpre[j]
+    float* __restrict__ sdst = first ? a.dY + grow0 * a.ldy : a.dpre + (size_t)j * a.pre_stride + grow0 * a.ldp;
+    const int sld = first ? a.ldy : a.ldp;
+    // pre[j - 1] of this wave's accumulator positions: 3 CT wave-loads of 1 KiB, in flight under the whole K loop
+    {
+      const gchar* pfw = uniform_gptr(a.pre + (size_t)(j - 1) * a.pre_stride + rc_frag_tile<CT>(g, wave, 0, 0));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) pf[rt][ct] = gload4(pfw + (rt * CT + ct) * 1024, lane16);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[rt][ct][r] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) b0[ct] = gload4(Wf, lane16 + ct * 1024u);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const f32x4*>(abase + rt * RC_USERS * LDA);
+    gchar* sdw = uniform_gptr(sdst);
+    RcSweep<QP, LDA> sw;
+    sw.init(tid, sld);
+    for (int ks = 0; ks < KS; ks += 2) {
+      const int k2 = ks + 2 < KS ? ks + 2 : ks;
+      rc_kstep<CT, LDA, 2, false, 0>(acc, a0, b0, a1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, sw);
+      rc_kstep<CT, LDA, 1, false, 0>(acc, a1, b0, a0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, sw);
+    }
+    if (j <= 2) RC_STAMP(2 + 3 * (2 - j));
+
+    // epilogue: PReLU', slope partial; the result replaces the tile (or, below layer 1, goes straight to HBM)
+    float ssum = 0.f;
+    __syncthreads();   // every wave is done reading the tile (and the previous layer's redf has been read)
+    float* __restrict__ obase = Act + (16 * wr + 4 * lq) * LDA + 16 * CT * wc + li;
+    float* __restrict__ gbase = a.dpre + (grow0 + 16 * wr + 4 * lq) * a.ldp + 16 * CT * wc + li;   // dpre[0]
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = pf[rt][ct][r], d = acc[rt][ct][r];
+          const bool pos = p > 0.f;
+          const float o = pos ? d : slope * d;
+          ssum += pos ? 0.f : d * p;
+          if (lastl) gbase[(size_t)(RC_USERS * rt + r) * a.ldp + 16 * ct] = o;
+          else obase[(RC_USERS * rt + r) * LDA + 16 * ct] = o;
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ssum += __shfl_down(ssum, off, 64);
+    if (lane == 0) redf[wave] = ssum;
+    __syncthreads();   // also: the new tile is complete
+    if (tid == 0) a.alpha_part[(size_t)(j - 1) * a.alpha_part_stride + g] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+    if (j <= 2) RC_STAMP(4 + 3 * (2 - j));
   }
 #ifdef RC_STAMPS
   RC_STAMP(10);
