@@ -40,6 +40,10 @@ int sdrm_debug_set_skinny(sdrm_engine* e, int on);
  * to fp32 summation order; the stacked rows of that step are in the GROUPED order (elementwise.h), which sdrm_get_train_outputs
  * / sdrm_get_preacts undo.  Refused between sdrm_train_backward_begin and _finish; drops a pending train forward. */
 int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
+/* Strip-owned weight gradients (csrc/wgrad2.h: every weight gradient of a step in one balanced round of one work-group per CU,
+ * bias gradients from the ones column of the layer inputs) behind the row-owned forward: 1 (default) on, 0 the batched 64x64-tile
+ * split-K launch; also env SDRM_WGRAD_STRIPS.  Takes effect with the next backward. */
+int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on);
 /* 1 when this engine's shape qualifies for the row-owned forward (its fragment-packed weight copies exist). */
 int sdrm_debug_rowchain_available(const sdrm_engine* e);
 /* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;

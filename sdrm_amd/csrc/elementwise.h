@@ -32,6 +32,8 @@ struct EmbTabArgs {
   const float* temb; const float* We; const float* be; const float* W0; const float* b0;
   float* Etab; float* W0c; float* B0tab;
   int L, W, T, LP, WP, K0;
+  int ones_col;   // pad column of B0tab that holds 1.0 in every row (-1: none): the layer-0 pre-activation of that column is then 1
+                  // in every stacked row, the "ones column" the strip-owned weight gradients take the bias gradients from (wgrad2.h)
 };
 
 // sum_t x[t*sx] * y[t*sy]: the table kernels are pure latency chains, so each batch issues 16 + 16
@@ -86,7 +88,7 @@ __device__ __forceinline__ void emb_tables_row(const EmbTabArgs& a, int t, float
   for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
     const float s = (w < a.W) ? dot_unrolled(a.W0 + (size_t)w * ldw + a.L, er, a.T) : 0.f;
     a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
-    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : 0.f;
+    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : (w == a.ones_col ? 1.f : 0.f);
   }
 }
 

@@ -58,6 +58,7 @@ struct RowChainArgs {
   const float* slope0; const float* slopeh;
   // outputs, grouped stacked rows
   float* U; int K0, LPs; int* tdev;
+  int ones_col;                             // pad column of U set to 1.0 in every row (-1: none), see wgrad2.h
   float* pre; size_t pre_stride; int ldp;   // pre[k] = pre + k * pre_stride, [MP][ldp]
   float* act;                               // activations prelu(pre[k]) in the same layout (null: not stored)
   float* Y; int ldy;
@@ -334,6 +335,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
             vQ[k] = k3 ? 2.f * (x + MU * ee) : 0.f;
           }
         }
+      }
+      if (c == (a.ones_col & ~3)) {   // the ones column (a pad column: layer 0's weights are zero there)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == (a.ones_col & 3)) vP[k] = vS[k] = vQ[k] = 1.f;
       }
       *reinterpret_cast<float4*>(Act + su * LDA + c) = make_float4(vP[0], vP[1], vP[2], vP[3]);
       *reinterpret_cast<float4*>(Act + (RC_USERS + su) * LDA + c) = make_float4(vS[0], vS[1], vS[2], vS[3]);

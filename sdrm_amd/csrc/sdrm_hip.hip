@@ -22,6 +22,7 @@
 #include "select.h"
 #include "skinny.h"
 #include "skinny_train.h"
+#include "wgrad2.h"
 
 using namespace sdrm;
 
@@ -54,6 +55,7 @@ struct Tuning {
   int wgrad_round = 1280;        // SDRM_WGRAD_ROUND: ... unless ONE round (this many work-groups) already gives eight slices or more
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
   int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
+  int strips = 1;                // SDRM_WGRAD_STRIPS: strip-owned weight gradients (csrc/wgrad2.h) behind the row-owned forward: 0 off
   int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
                                  // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
 };
@@ -75,6 +77,10 @@ struct sdrm_engine {
   float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
                                      // the weight gradients of that step read their operand without PReLU on load
   bool cur_act = false;              // the last train_forward stored them
+  int ones_col = -1;                 // pad column round_up(W, 4) < WP of the layer inputs that carries 1.0 (the padded biases put it there,
+                                     // the row-owned forward's staging into U): column ones_col of a weight-gradient slab is then the
+                                     // bias gradient (csrc/wgrad2.h); -1: none
+  bool bwd_strips = false;           // this backward's weight gradients: the strip-owned launch (bias gradients in slab column ones_col)
   float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
@@ -142,7 +148,7 @@ struct sdrm_engine {
 typedef sdrm_engine::SampleStateT SampleState;
 
 enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_SMP_L0, PC_SMP_HIDDEN,
-                 PC_SMP_OUT, PC_COUNT };
+                 PC_SMP_OUT, PC_ROW_FWD, PC_WGRAD_STRIPS, PC_COUNT };
 // the template arguments are <LOADA,LOADB,XFA,XFB,EPI> of gemm_kernel (what rocprofv3 prints after the tile type)
 static const char* kProfNames[PC_COUNT] = {
     "train: gemm_kernel<0,0,0,0,9> fwd layer0 (row-table bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
@@ -151,7 +157,9 @@ static const char* kProfNames[PC_COUNT] = {
     "train: gemm_batch_kernel<1,1,0,1,4> wgrad of all layers in one launch (prelu-in, split-K slabs)",
     "train: gemm_kernel<1,1,0,0,4> wgrad layer0 (split-K slabs)",
     "sample: gemm_kernel<0,0,0,0,10> fwd layer0 (bias table, prelu epilogue)", "sample: gemm_kernel<0,0,0,0,10> fwd hidden (bias, prelu epilogue)",
-    "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)"};
+    "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)",
+    "train: k_row_fwd row-owned forward (staging + all layers + loss partial sums, one work-group per CU)",
+    "train: k_wgrad_strips weight gradients of all layers (strip-owned split-K, one work-group per CU)"};
 
 namespace {
 
@@ -405,7 +413,9 @@ int wgrad_tiles(const Tuning& tn, int Nout, int Kin) {
   return ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
 }
 
-void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks, float* gdst = nullptr) {
+// bias_col >= 0: the weight gradients were the strip-owned launch (wgrad2.h) - the bias gradient of a layer is column bias_col of
+// its weight-gradient slabs (a strided [out] x 1 job) instead of the column-sum slabs of the 64x64-tile kernel
+void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks, float* gdst = nullptr, int bias_col = -1) {
   float* gbase = gdst ? gdst : e->g;
   const int L = e->L, W = e->W, T = e->T, H = e->H;
   int n = 0;
@@ -424,19 +434,22 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
   add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
   add(e->off_w0, W, L + T, L + T, L, e->slab0, e->K0, (size_t)e->WP * e->K0, S0, e->W0c, e->K0);
   tab.j[n - 1].dstF = e->W0f;
-  add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
+  if (bias_col >= 0) add(e->off_b0, W, 1, 1, 1, e->slab0 + bias_col, e->K0, (size_t)e->WP * e->K0, S0, e->b0c, 1);
+  else add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
   // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
   add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
   if (H >= 1) {
     add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
     tab.j[n - 1].dstF = e->Whf;
-    add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
+    if (bias_col >= 0) add(e->off_bh, W, 1, 1, 1, e->slabH + bias_col, e->WP, (size_t)e->WP * e->WP, H * SH, e->bhc, 1);
+    else add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
     add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
         dgrad_blocks);
   }
   add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
   tab.j[n - 1].dstF = e->Wof;
-  add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
+  if (bias_col >= 0) add(e->off_bo, L, 1, 1, 1, e->slabO + bias_col, e->WP, (size_t)e->LP * e->WP, SO, e->boc, 1);
+  else add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
   tab.n_adam = n;
   // finalize-only job: the one-hot columns of the layer-0 slabs -> dense dC0T[W][TP] for the emb backward
   add(0, W, 0, 0, T + 1, e->slab0 + e->LP, e->K0, (size_t)e->WP * e->K0, S0, nullptr, 0);
@@ -466,11 +479,71 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
   return SDRM_OK;
 }
 
+// Strip-owned weight gradients (csrc/wgrad2.h): every weight gradient of the step in one balanced round of one work-group per CU.
+// Taken by the one-call backward when the forward was the row-owned one (the operands are stored as the kernel reads them:
+// activations, a ones column for the bias gradients) and the slices stay within the slab count.
+bool use_strips(const sdrm_engine* e) {
+  return e->cur_grouped && e->cur_act && e->ones_col >= 0 && e->tune.strips > 0 && e->H + 2 <= WG2_MAX_PROBLEMS && e->WP >= 128 && e->WP <= 352;
+}
+
+template <int NT>
+int launch_wgrad_strips_nt(sdrm_engine* e, const Wg2Args& a, double flops, hipStream_t st) {
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_WGRAD_STRIPS);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_WGRAD_STRIPS);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  SDRM_LAUNCH(e, (k_wgrad_strips<NT>), dim3((unsigned)(a.units * a.slices)), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  return SDRM_OK;
+}
+
+int launch_wgrad_strips(sdrm_engine* e, int MP, double flops, hipStream_t st) {
+  const int H = e->H;
+  Wg2Args a{};
+  int ktiles[WG2_MAX_PROBLEMS], n = 0;
+  auto problem = [&](const float* A, int lda, const float* B, int ldb, float* slab, int kin, size_t slab_rows) {
+    a.p[n].A = A; a.p[n].lda = lda; a.p[n].B = B; a.p[n].ldb = ldb; a.p[n].slab = slab; a.p[n].ldc = kin;
+    a.p[n].slab_stride = slab_rows * (size_t)kin;
+    ktiles[n++] = kin / 32;
+  };
+  auto actk = [&](int k) { return e->act + (size_t)k * e->MPmax * e->WP; };
+  problem(dpre_buf(e, 0), e->WP, e->U, e->K0, e->slab0, e->K0, (size_t)e->WP);
+  problem(e->dY, e->LP, actk(H), e->WP, e->slabO, e->WP, (size_t)e->LP);
+  const int units = [&] { int t = e->K0 / 32 + (H + 1) * (e->WP / 32); return (t + 3) / 4; }();
+  int S = 256 / units;
+  if (S < 1) S = 1;
+  if (S > S_MAX) S = S_MAX;
+  const int kchunk = round_up((MP + S - 1) / S, WG2_BK);
+  const int slices = (MP + kchunk - 1) / kchunk;
+  for (int k = H; k >= 1; --k)   // the shared hidden layer: one problem per application, slabs [application][slice]
+    problem(dpre_buf(e, k), e->WP, actk(k - 1), e->WP, e->slabH + (size_t)(k - 1) * slices * e->WP * e->WP, e->WP, (size_t)e->WP);
+  if (wg2_plan(ktiles, n, a) != units) return fail(e, SDRM_ERR_SHAPE, "strip-owned weight gradients: plan does not fit");
+  a.slices = slices; a.rows = MP; a.kchunk = kchunk;
+  e->bwd_S0 = e->bwd_SH = e->bwd_SO = slices;
+  e->bwd_strips = true;
+  switch (e->WP / 32) {
+    case 4: return launch_wgrad_strips_nt<4>(e, a, flops, st);
+    case 5: return launch_wgrad_strips_nt<5>(e, a, flops, st);
+    case 6: return launch_wgrad_strips_nt<6>(e, a, flops, st);
+    case 7: return launch_wgrad_strips_nt<7>(e, a, flops, st);
+    case 8: return launch_wgrad_strips_nt<8>(e, a, flops, st);
+    case 9: return launch_wgrad_strips_nt<9>(e, a, flops, st);
+    case 10: return launch_wgrad_strips_nt<10>(e, a, flops, st);
+    default: return launch_wgrad_strips_nt<11>(e, a, flops, st);
+  }
+}
+
 EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
   EmbTabArgs a{};
   a.temb = e->temb; a.We = e->p + e->off_we; a.be = e->p + e->off_be; a.W0 = e->p + e->off_w0; a.b0 = e->p + e->off_b0;
   a.Etab = e->Etab; a.W0c = e->W0c; a.B0tab = for_sampling ? e->B0tab : nullptr;
   a.L = e->L; a.W = e->W; a.T = e->T; a.LP = e->LP; a.WP = e->WP; a.K0 = e->K0;
+  a.ones_col = e->ones_col;
   return a;
 }
 
@@ -512,7 +585,7 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.mode = mode; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.step = (uint32_t)step; a.row0 = row0; a.nd = nd;
   a.W0f = e->W0f; a.Whf = e->Whf; a.Wof = e->Wof; a.bh = e->bhc; a.bo = e->boc; a.B0tab = e->B0tab; a.ldtab = e->WP;
   a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
-  a.U = e->U; a.K0 = e->K0; a.LPs = e->LP; a.tdev = e->tdev;
+  a.U = e->U; a.K0 = e->K0; a.LPs = e->LP; a.tdev = e->tdev; a.ones_col = e->ones_col;
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
   a.act = e->act;
   a.loss_part = e->loss_part;
@@ -695,6 +768,12 @@ int sdrm_debug_set_rowchain(sdrm_engine* e, int mode) {
 
 int sdrm_debug_rowchain_available(const sdrm_engine* e) { return e && e->W0f ? 1 : 0; }
 
+int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.strips = on ? 1 : 0;
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
   e->tune.skinny = on ? 1 : 0;
@@ -777,6 +856,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_AR_BUCKETS")) e->tune.ar_buckets = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
   e->MPmax = round_up(RC_ROWS * ((max_rows + RC_USERS - 1) / RC_USERS), 128);   // either stacked row order fits
@@ -810,6 +890,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     HIP_TRY(e, dalloc(&e->W0f, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->Whf, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->Wof, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->act, (size_t)(H + 1) * e->MPmax * e->WP));
+    if (round_up(W, 4) < e->WP) e->ones_col = round_up(W, 4);
   }
   HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
@@ -826,6 +907,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   {
     const float one = 1.0f;
     HIP_TRY(e, hipMemcpy(e->one_dev, &one, 4, hipMemcpyHostToDevice));
+    // the ones column: pad entry ones_col of the hidden layer's padded bias is 1 (its weight row there is zero, so the
+    // pre-activation and the activation of that pad column are 1 in every row; the next layer's weight column there is zero, so
+    // nothing else changes); layer 0's comes from B0tab (k_emb_tables), U's from the row-owned forward's staging
+    if (e->ones_col >= 0) HIP_TRY(e, hipMemcpy(e->bhc + e->ones_col, &one, 4, hipMemcpyHostToDevice));
   }
   HIP_TRY(e, dalloc(&e->U, MP * e->K0)); HIP_TRY(e, dalloc(&e->pre, (size_t)(H + 1) * MP * e->WP));
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
@@ -1057,6 +1142,7 @@ namespace {
 // loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
 int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
+  e->bwd_strips = false;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_grouped ? 1 : 0;
@@ -1129,6 +1215,7 @@ int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
                                        e->dbHs + (size_t)(k - 1) * SH * e->WP, st, Prof{e, PC_WGRAD, flH}, cfg_w)));
     return SDRM_OK;
   }
+  if (with_wgrad0 && use_strips(e)) return launch_wgrad_strips(e, MP, fl0 + flO + H * flH, st);
   std::vector<WgradSpec> w;
   std::vector<double> fl;
   if (with_wgrad0) {
@@ -1159,7 +1246,7 @@ enum { BUCKET_FIRST = 1, BUCKET_SECOND = 2, BUCKET_BOTH = 3 };
 // slab reduction into the flat gradient (written where the caller wants it, e.g. a DDP bucket - no copy afterwards)
 int backward_finalize(sdrm_engine* e, float* gout, int which, hipStream_t st) {
   JobTable tab;
-  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout);
+  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout, e->bwd_strips ? e->ones_col : -1);
   JobTable sel{};
   for (int j = 0; j < tab.n; ++j) {
     const bool second = tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P;

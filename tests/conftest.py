@@ -40,11 +40,13 @@ def engine_cls():
 
     class TestEngine(Engine):
         def debug_set(self, **kw):
-            if kw.get("tile") == "row":
+            if kw.get("tile") in ("row", "row-tiles"):
                 if not self.rowchain_available:
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope")
-                kw = dict(kw, tile=None, rowchain=2)
+                # "row": the row-owned forward with the strip-owned weight gradients behind it (the default pairing);
+                # "row-tiles": the same forward with the batched 64x64-tile split-K launch
+                kw = dict(kw, tile=None, rowchain=2, wgrad_strips=kw["tile"] == "row")
             return super().debug_set(**kw)
 
     return TestEngine

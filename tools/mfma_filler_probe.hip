@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <vector>
 
+#ifndef NACC32
+#define NACC32 8
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -18,7 +21,7 @@ enum { F_VALU = 0, F_LDS = 1, F_GLOBAL = 2, F_VALU_DEP = 3 };
 
 template <int MF, int NF, int KIND>
 __global__ __launch_bounds__(256, 1) void k_probe(const float* __restrict__ src, float* __restrict__ out, unsigned long long* stamps, int iters) {
-  constexpr int NACC = MF == 16 ? 33 : 8;
+  constexpr int NACC = MF == 16 ? 33 : NACC32;
   __shared__ __attribute__((aligned(16))) float lds[8192];
   const int tid = threadIdx.x;
   for (int i = tid; i < 8192; i += 256) lds[i] = src[i];
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256, 1) void k_probe(const float* __restrict__ src,
 
 template <int MF, int NF, int KIND>
 int run(const char* label, const float* src, float* out, unsigned long long* st) {
-  const int iters = 200, G = 256, NACC = MF == 16 ? 33 : 8;
+  const int iters = 200, G = 256, NACC = MF == 16 ? 33 : NACC32;
   hipLaunchKernelGGL((k_probe<MF, NF, KIND>), dim3(G), dim3(256), 0, 0, src, out, st, iters);
   hipLaunchKernelGGL((k_probe<MF, NF, KIND>), dim3(G), dim3(256), 0, 0, src, out, st, iters);
   CHECK(hipDeviceSynchronize());
