@@ -124,6 +124,12 @@ __device__ __forceinline__ void gstore4(gchar* base, uint32_t off, float4 v) {
   f32x4 w = {v.x, v.y, v.z, v.w};
   *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(base + off) = w;
 }
+// the same with the non-temporal hint: bytes nobody reads before the weight gradients, a whole backward chain later (U, the
+// activations) - they should not push the pre-activations and Y, which the loss seeds and the dgrads read next, out of the caches
+__device__ __forceinline__ void gstore4_nt(gchar* base, uint32_t off, float4 v) {
+  f32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(base + off));
+}
 
 // position of a thread in the sweep of the activation tile (one float4 per thread and chunk): chunk j covers the flat quad
 // indices j * 256 + tid, row = f / QP, quad = f % QP; stepping a chunk adds 256 = (256 / QP) rows + (256 % QP) quads, with one
@@ -205,9 +211,10 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
             so = sw.g_off;
             sw.next();
           } else if (ph == 1) {
-            gstore4(sdst, so, v);
+            if (ACT) gstore4(sdst, so, v);   // pre-activations: read again by the first dgrad
+            else gstore4_nt(sdst, so, v);    // U: read again by the layer-0 weight gradient only
           } else {
-            gstore4(adst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
+            gstore4_nt(adst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
           }
         }
       } else {
