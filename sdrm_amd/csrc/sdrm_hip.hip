@@ -549,7 +549,7 @@ EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
 
 int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
   const EmbTabArgs a = emb_args(e, for_sampling);
-  SDRM_LAUNCH(e, k_emb_tables, dim3(e->T + 1), dim3(256), 2 * e->T * sizeof(float), st, a);
+  SDRM_LAUNCH(e, k_emb_tables, dim3(e->T + 1), dim3(1024), 2 * e->T * sizeof(float), st, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
 }
