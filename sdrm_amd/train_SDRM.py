@@ -392,9 +392,18 @@ def _decode(eng, vae_net, latents):
     `sdrm_engine_decode = True` and keeps the `Linear -> Tanh -> Linear` decoder) runs on the engine's MFMA GEMM
     (`sdrm_vae_decode`); any other decode hook is called as the module it is."""
     ts = decoder_tensors(vae_net) if (isinstance(vae_net, VAE) or getattr(vae_net, "sdrm_engine_decode", False)) else None
-    if ts is None:
+    if ts is None or not engine_decode_pays(latents.shape[0], ts[0].shape[0], ts[2].shape[0]):
         return vae_net.decode(latents)
     return eng.vae_decode(latents, *ts)
+
+
+def engine_decode_pays(n_users: int, hidden: int, n_items: int) -> bool:
+    """Where the engine's decode beats the PyTorch module it replaces (measured, profiles/r02_next_rows_bench.txt and
+    r03_next_rows_bench.txt): ML-1M (5429 x 3125, hidden 600) 246 us against 301; ML-100k (843 x 1008) 60 against 53 - five
+    staging launches on a 0.8 GFLOP problem - and ADM (9558 x 8582, hidden 200: a 200-deep contraction) 414 against 403 lose.
+    So: a hidden width that fills the K loop, and enough work to amortise the staging.  `sdrm_vae_decode` itself is correct at
+    every shape (tests/test_vae_decode.py); this only routes the hook."""
+    return hidden >= 256 and float(n_users) * float(n_items) * float(hidden) >= 4e9
 
 
 @torch.no_grad()
