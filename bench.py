@@ -224,22 +224,31 @@ def _profile_file(pattern: str):
     return files[-1] if files else None
 
 
+def kernel_needle(kernel_class: str):
+    """What identifies the kernel of a profile class inside a rocprofv3 kernel name: the template arguments of the GEMM classes
+    ("gemm_kernel<0,0,1,0,1>" -> ", 0, 0, 1, 0, 1>("), or the name of the stand-alone kernels ("k_wgrad_strips")."""
+    import re
+    m = re.search(r"<(\d+),(\d+),(\d+),(\d+),(\d+)>", kernel_class)
+    if m:
+        return ", " + ", ".join(m.groups()) + ">("
+    m = re.search(r"\b(k_[a-z0-9_]+)", kernel_class)
+    return "::" + m.group(1) + "<" if m else None
+
+
 def pmc_traffic(kernel_class: str, lib_hash: str):
     """HBM bytes per launch of the dominant kernel REPLAYED from the committed PMC passes (profiles/*pmc_traffic.json,
     made by tools/pmc_summary.py from two separate `rocprofv3 --pmc` runs of this same command; gfx950 FETCH_SIZE
     correction applied there) - counters cannot be read inside an unprofiled run.  Returns (bytes or None, provenance):
     the value is dropped when the file was collected from other kernel sources than the library loaded now."""
-    import re
     path = _profile_file("*pmc_traffic.json")
-    m = re.search(r"<(\d+),(\d+),(\d+),(\d+),(\d+)>", kernel_class)
-    if not path or not m:
+    needle = kernel_needle(kernel_class)
+    if not path or not needle:
         return None, {"file": None}
     data = json.load(open(path))
     src = {"file": os.path.basename(path), "git_head": data.get("git_head"), "source_hash": (data.get("source_hash") or "")[:16] or None,
            "matches_loaded_library": bool(data.get("source_hash")) and data.get("source_hash") == lib_hash}
     if not src["matches_loaded_library"]:
         return None, src
-    needle = ", " + ", ".join(m.groups()) + ">("
     for name, v in data.get("kernels", {}).items():
         if needle in name:
             # the same template serves train launches (24576 rows: the largest grid) and sampling launches
@@ -255,15 +264,13 @@ def pmc_mfma_busy(kernel_class: str, lib_hash: str):
     """Matrix-pipe busy cycles per SIMD and launch of the dominant kernel, replayed from the committed SQ counter pass
     (profiles/*pmc_sq.json, made by tools/pmc_sq.py from `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES ...` of this command);
     None when that pass belongs to other kernel sources."""
-    import re
     path = _profile_file("*pmc_sq.json")
-    m = re.search(r"<(\d+),(\d+),(\d+),(\d+),(\d+)>", kernel_class)
-    if not path or not m:
+    needle = kernel_needle(kernel_class)
+    if not path or not needle:
         return None
     data = json.load(open(path))
     if not data.get("source_hash") or data.get("source_hash") != lib_hash:
         return None
-    needle = ", " + ", ".join(m.groups()) + ">("
     for name, rows in data.get("kernels", {}).items():
         if needle in name and rows:
             rows = sorted(rows, key=lambda r: r["grid_size"])

@@ -569,8 +569,19 @@ bool use_rowchain(const sdrm_engine* e, int B) {
 
 template <int CT>
 int launch_row_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStream_t st) {
+  // profile class: the algorithmic flops of the H + 2 layers of the three passes (staging, loss sums and the streamed copies ride along)
+  const double flops = 2.0 * 3 * a.B * ((double)e->W * e->L + (double)e->H * e->W * e->W + (double)e->L * e->W);
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_ROW_FWD);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_ROW_FWD);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
   SDRM_LAUNCH(e, (k_row_fwd<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
 }
 

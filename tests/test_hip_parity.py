@@ -382,6 +382,41 @@ def test_weight_gradients_at_any_slice_count(engine_cls, monkeypatch, dims, slic
     assert l2 == l1 and np.array_equal(g2, g1)      # the two-call backward adds the same slices in the same order
 
 
+@pytest.mark.parametrize("dims", [(136, 136, 12, 2, 75), (340, 340, 78, 1, 300), (100, 100, 7, 0, 40)])
+def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
+    """Behind the row-owned forward (grouped row order, stored activations, ones column) the three backward forms must agree:
+    one call with the strip-owned weight gradients (bias gradients from the ones column of the slabs), one call with the
+    batched 64x64-tile launch (bias gradients from its column sums), and the two-call form (sdrm_train_backward_begin /
+    _finish, what the two-bucket exchange of the sharded step uses) - and all of them with the per-layer path."""
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=26), H)
+    x0 = synth.synth_latents(B, L, seed=27)
+    eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=28)
+
+    def grads(path, two_call=False):
+        e = engine_cls(L, W, T, H, B).debug_set(tile=path)
+        e.set_params(init)
+        e.train_forward(x0, noise=eps, t=t, keep=keep)
+        if two_call:
+            loss = float(e.train_backward_begin().cpu())
+            e.train_backward_finish()
+        else:
+            loss = float(e.train_backward().cpu())
+        g = e.get_grads().cpu().numpy()
+        e.adam_step(1e-3)
+        p = e.get_params().cpu().numpy()
+        e.close()
+        return loss, g, p
+
+    ref = grads(-1)
+    for path, two_call in (("row", False), ("row-tiles", False), ("row", True)):
+        loss, g, p = grads(path, two_call)
+        assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0])
+        for (n, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(ref[1], (L, W, T, H))):
+            assert rel_l2(a, b) <= 2e-5 and rel_max(a, b) <= 1e-4, (path, two_call, n, rel_l2(a, b), rel_max(a, b))
+        assert rel_l2(p, ref[2]) <= 1e-5
+
+
 @pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("multires", [False, True])
 def test_philox_mode_sampling(engine_cls, multires, sampler_path, tile, fused):
