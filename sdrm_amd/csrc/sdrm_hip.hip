@@ -897,7 +897,8 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->Whc, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->bhc, e->WP));
   HIP_TRY(e, dalloc(&e->Woc, (size_t)round_up(e->LP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->boc, e->LP));
   HIP_TRY(e, dalloc(&e->WhcT, (size_t)round_up(e->WP, 128) * e->WP)); HIP_TRY(e, dalloc(&e->WocT, (size_t)round_up(e->WP, 128) * e->LP));
-  if (e->LP == e->WP && e->WP >= 128 && e->WP <= 352) {   // the row-owned forward's shape envelope (rowchain.h)
+  if (L == W && e->WP >= 128 && e->WP <= 352) {   // the row-owned forward's shape envelope (rowchain.h); L == W (every call site of the
+                                                  // reference): the ones column round_up(W, 4) must be a pad column of U as well
     HIP_TRY(e, dalloc(&e->W0f, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->Whf, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->Wof, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->act, (size_t)(H + 1) * e->MPmax * e->WP));
