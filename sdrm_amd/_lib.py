@@ -93,6 +93,7 @@ SIGNATURES = {
     "sdrm_debug_set_rowchain": (c_int, [c_void_p, c_int]),
     "sdrm_debug_rowchain_available": (c_int, [c_void_p]),
     "sdrm_debug_set_wgrad_strips": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_dgrad_rows": (c_int, [c_void_p, c_int]),
     "sdrm_debug_comm_handle": (c_void_p, [c_void_p]),
     "sdrm_debug_plan_wgrad": (c_int, [c_int, c_int, c_int, C.POINTER(c_int), C.POINTER(c_int)]),
     "sdrm_debug_gemm_time": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_float), c_void_p]),

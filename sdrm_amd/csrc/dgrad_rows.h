@@ -1,0 +1,259 @@
+// Row-owned input gradient (dgrad) of one eps-net layer behind the row-owned forward (rowchain.h), gfx950:
+//   out[r][c] = (sum_k G[r][k] * W[k][c]) * prelu'(pre[r][c]),   slope partial = sum acc * min(pre, 0)
+// (train_SDRM.py:336, loss.backward(): the input gradients of the hidden and output Linears with PReLU' folded in).
+//
+// Ownership as in the forward - ONE work-group per CU owns 96 stacked rows and ALL NP output columns, 4 waves as 2 x 2, a wave
+// 3 row tiles x CT column tiles of v_mfma_f32_16x16x4_f32 (33 accumulator quads at NP = 352) - but nothing lives in LDS:
+//   * G fragments come straight from global memory: lane (row li, k group lq) takes the 16 bytes G[row][16 ks + 4 lq ..], a
+//     wave-load is 16 rows x 64 B; the work-group's 96 rows are one contiguous block of HBM, read once (the partner wave's
+//     copy and the second half of every 128-byte line hit in L2), fetched TWO K-steps ahead (four register sets);
+//   * W fragments come from L2 out of the fragment-packed copy of the layer's weight in [k = out][n = in] order (k_adam's
+//     dstFT), one K-step ahead, exactly as in the forward;
+//   * no LDS, no barrier, no VALU in the K loop: every memory instruction sits behind an MFMA, where it is free (measured
+//     at the ISA level, profiles/r03_mfma_shadow_asm_probe.txt: 132 MFMAs + 11 consumed wave-loads = 1.02 x the MFMAs alone);
+//   * the MFMA operands are SWAPPED (weights as srcA, gradients as srcB): the tile comes out transposed, so a lane holds four
+//     consecutive COLUMNS of one row - pre-activations in and input gradients out are 16-byte accesses of row-major memory,
+//     and the pre-activation quads are requested in the shadows of the last two K-steps.
+// 24576 stacked rows = 256 work-groups = one round of the chip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rowchain.h"
+
+#ifndef DR_DIAG   // diagnostic builds only: bit0 drops the W fragment loads of the K loop, bit1 the G fragment loads, bit2 ADDS an s_nop 1 in front of every MFMA
+#define DR_DIAG 0
+#endif
+#ifndef DR_PIECE_STRIDE
+#define DR_PIECE_STRIDE 3
+#endif
+
+namespace sdrm {
+
+// Raw buffer loads: base in a 4-SGPR resource, a per-lane 32-bit offset, a scalar offset advanced on the scalar unit, an
+// immediate - ONE instruction and no VALU (the global_load form of rowchain.h costs a 64-bit VALU add per load, and with one
+// wave per SIMD a VALU instruction and the load waiting for it stall the MFMA stream: measured here, 32 cycles per load).
+// Out-of-range offsets return zero instead of faulting.
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc make_brsrc(const void* p, uint32_t bytes) {   // p wave-uniform
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(brsrc r, uint32_t voff, uint32_t soff) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+struct DgradRowsArgs {
+  const float* G; int ldg;      // incoming gradient [MP][ldg], columns [0, NP) are the reduction axis
+  const float* WfT;             // fragment-packed [NP/16][NP/16][64][4]: element (n = in, k = out), wfrag_index(n, k, NP / 16)
+  const float* pre; int ldp;    // pre-activations of the layer below [MP][ldp]
+  const float* slope;           // its PReLU slope
+  float* out; int ldo;          // [MP][ldo]
+  float* slope_part;            // [gridDim.x]
+  unsigned long long* stamps;   // diagnostic builds only (-DDR_STAMPS): 8 slots per work-group
+};
+
+#ifdef DR_STAMPS
+#define DR_STAMP(i) do { if (tid == 0) st_[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DR_STAMP(i) do { } while (0)
+#endif
+
+// one K-step of phase PH (= K-step index mod 4): 12 * CT MFMAs out of (A[PH], B[PH & 1]); in their shadows the W fragments of the
+// next K-step (NB = CT of them -> B[(PH + 1) & 1]), the G fragments of the K-step after that (NA = 3 -> A[(PH + 2) & 3]), and NPRE
+// pre-activation quads (-> pq[PRE0 ..], flat index rt * CT + ct).  One basic block, every load pinned at its slot through an
+// opaque scalar base (see rc_kstep).
+template <int CT, int PH, int NA, int NB, int PRE0, int NPRE>
+__device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc gr, uint32_t gnext,
+                                         const uint32_t (&goff)[3], brsrc wr_, uint32_t wnext, uint32_t lane16, f32x4 (&pq)[3 * CT],
+                                         brsrc pr, const uint32_t (&poff)[3]) {
+  constexpr int NSLOT = 12 * CT, NPIECE = NB + NA + NPRE;
+  // the pieces go to the FRONT of the K-step, one per DR_PIECE_STRIDE MFMAs (behind an MFMA a load's issue is free)
+  constexpr int STRIDE = NPIECE > 0 ? (NSLOT / NPIECE >= DR_PIECE_STRIDE ? DR_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1)) : NSLOT;
+  static_assert(NPIECE <= NSLOT, "not enough MFMA slots for the pipeline pieces");
+  const f32x4 (&au)[3] = A[PH];
+  const f32x4 (&bu)[CT] = B[PH & 1];
+  f32x4 (&al)[3] = A[(PH + 2) & 3];
+  f32x4 (&bl)[CT] = B[(PH + 1) & 1];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) {
+    const int s = (e * CT + ct) * 3 + rt;
+    // swapped operands: the tile comes out transposed.  Written as asm with the accumulator tied in place: through the builtin
+    // the register allocator renames accumulators in the last K-step of the loop body and copies them back at its top
+    // (~250 v_accvgpr_mov per trip).  The price: the compiler's hazard recogniser does not see an MFMA here: dr_begin /
+    // dr_settle guard the two places where compiler-made VALU code meets the accumulators (their zeros, their first read);
+    // tests/test_isa_lint.py checks the generated code for any other
+    if (DR_DIAG & 4) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bu[ct][e]), "v"(au[rt][e]));
+    else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bu[ct][e]), "v"(au[rt][e]));
+    if (s % STRIDE == 0 && s / STRIDE < NPIECE) {
+      const int p = s / STRIDE;
+      if (p < NB) {
+        if (!(DR_DIAG & 1)) {
+          uint32_t so = wnext + (p / 4) * 4096;   // opaque at this slot: pins the load here
+          asm volatile("" : "+s"(so));
+          bl[p] = bload4(wr_, lane16 + (p % 4) * 1024, so);
+        }
+      } else if (p < NB + NA) {
+        if (!(DR_DIAG & 2)) {
+          uint32_t so = gnext;
+          asm volatile("" : "+s"(so));
+          al[p - NB] = bload4(gr, goff[p - NB], so);
+        }
+      } else {
+        const int q = PRE0 + (p - NB - NA), rt2 = q / CT, ct2 = q % CT;
+        uint32_t so = ct2 * 64;
+        asm volatile("" : "+s"(so));
+        pq[q] = bload4(pr, poff[rt2], so);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the last PEEL K-steps, straight-line: K-step KS - PEEL + J has phase J & 3 (KS - PEEL is a multiple of four), fetches what is
+// still to come, and takes its share of the 3 * CT pre-activation quads - spread over all of them: in the last two K-steps alone
+// they are a 35 MB burst chip-wide, more than HBM delivers in that time
+template <int CT, int KS, int PEEL, int J>
+__device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc Gw, const uint32_t (&goff)[3],
+                                        brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw, const uint32_t (&poff)[3]) {
+  if constexpr (J < PEEL) {
+    constexpr int K = KS - PEEL + J, NQ = 3 * CT;
+    constexpr int NA = K + 2 < KS ? 3 : 0, NB = K + 1 < KS ? CT : 0;
+    constexpr int PRE0 = J * NQ / PEEL, NPRE = (J + 1) * NQ / PEEL - PRE0;
+    constexpr uint32_t WSTEP = 2u * CT * 1024u;
+    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), goff, Wf, (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw,
+                                            poff);
+    dr_peel<CT, KS, PEEL, J + 1>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
+  }
+}
+
+// before the first dr_kstep: every accumulator's zero is materialised in ITS register here (an opaque read-modify of each: the
+// compiler can no longer write the constant lazily, right in front of the first asm MFMA that reads it), then the wait states
+// a VALU write needs before an MFMA may read it
+template <int CT>
+__device__ __forceinline__ void dr_begin(f32x4 (&acc)[3][CT]) {
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
+  asm volatile("s_nop 7");
+}
+
+// after the last dr_kstep: the wait states an MFMA result needs before a VALU instruction may read it (the asm MFMAs are opaque to
+// the compiler), as a dependence of every accumulator: volatile asm statements keep their order, so every read follows the s_nops
+template <int CT>
+__device__ __forceinline__ void dr_settle(f32x4 (&acc)[3][CT]) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]));
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      if (rt + ct > 0) asm volatile("" : "+a"(acc[rt][ct]));
+}
+
+template <int CT>
+__global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs a) {
+  constexpr int NP = 32 * CT, NCT = 2 * CT, KS = NP / 16, NQ = 3 * CT;
+  static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lq = lane >> 4;
+  const size_t grow0 = (size_t)RC_ROWS * blockIdx.x;
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+#ifdef DR_STAMPS
+  unsigned long long st_[8] = {0};
+#endif
+  DR_STAMP(0);
+
+  // byte offsets of this lane's 16-byte pieces relative to the work-group's first row: G fragment of row tile rt (+ 64 ks),
+  // and the accumulator quad of (rt, ct) in pre / out (+ 64 ct): row 48 wr + 16 rt + li, columns 16 (CT wc + ct) + 4 lq ..
+  uint32_t goff[3], poff[3], ooff[3];
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) {
+    const int row = 48 * wr + 16 * rt + li;
+    goff[rt] = (uint32_t)((row * a.ldg + 4 * lq) * 4);
+    poff[rt] = (uint32_t)((row * a.ldp + 16 * CT * wc + 4 * lq) * 4);
+    ooff[rt] = (uint32_t)((row * a.ldo + 16 * CT * wc + 4 * lq) * 4);
+  }
+  const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(RC_ROWS * a.ldg * 4));
+  const brsrc Wf = make_brsrc(a.WfT + (size_t)(CT * wc) * 256, (uint32_t)((KS * NCT - CT * wc) * 1024));
+  const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(RC_ROWS * a.ldp * 4));
+  gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
+  const float slope = *a.slope;
+
+  f32x4 acc[3][CT];
+  f32x4 A[4][3];    // G fragments of K-step k live in A[k & 3] (fetched two K-steps ahead)
+  f32x4 B[2][CT];   // W fragments of K-step k in B[k & 1] (one K-step ahead)
+  f32x4 pq[NQ];
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // prologue: G fragments of K-steps 0 and 1, W fragments of K-step 0
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) {
+    A[0][rt] = bload4(Gw, goff[rt], 0u);
+    A[1][rt] = bload4(Gw, goff[rt], 64u);
+  }
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) B[0][ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
+
+  dr_begin<CT>(acc);
+  DR_STAMP(1);
+  constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;   // bytes of one K-step of the fragment-packed weights
+  // main loop: four K-steps per trip (the G sets rotate with period four, the W sets with period two); the last PEEL K-steps
+  // (PEEL = KS mod 4, at most ten, at least one trip left) are straight-line code and carry the pre-activation loads
+  constexpr int PEEL = KS % 4 == 2 ? (KS >= 14 ? 10 : (KS >= 10 ? 6 : 2)) : (KS >= 12 ? 8 : 4);
+  static_assert((KS - PEEL) % 4 == 0 && KS - PEEL >= 4, "the main loop takes whole trips of four K-steps");
+  for (uint32_t ks = 0; ks < (uint32_t)(KS - PEEL); ks += 4) {
+    dr_kstep<CT, 0, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 2), goff, Wf, (ks + 1) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 1, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 3), goff, Wf, (ks + 2) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 2, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 4), goff, Wf, (ks + 3) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 3, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
+  }
+  DR_STAMP(2);
+  dr_peel<CT, KS, PEEL, 0>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
+  DR_STAMP(3);
+  dr_settle<CT>(acc);
+  // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
+  float part4[4] = {0.f, 0.f, 0.f, 0.f};   // four chains: one wave per SIMD, nothing else hides a dependent FMA's latency
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const f32x4 p = pq[rt * CT + ct];
+      f32x4 v = acc[rt][ct];
+      asm("" : "+v"(v));   // one copy out of the accumulator registers, every use below reads it
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float m;
+        asm("v_min_f32 %0, 0, %1" : "=v"(m) : "v"(p[i]));   // min(pre, 0) without the canonicalising v_max fminf() puts in front
+        part4[i] = fmaf(v[i], m, part4[i]);
+        v[i] *= p[i] > 0.f ? 1.f : slope;
+      }
+      gstore4(Ow + ct * 64, ooff[rt], make_float4(v[0], v[1], v[2], v[3]));
+    }
+  float part = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (tid == 0) a.slope_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+#ifdef DR_STAMPS
+  DR_STAMP(4);
+  if (tid == 0 && a.stamps) {
+    st_[5] = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < 8; ++i) a.stamps[8 * (size_t)blockIdx.x + i] = st_[i];
+  }
+#endif
+}
+
+}  // namespace sdrm

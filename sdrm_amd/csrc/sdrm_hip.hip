@@ -22,6 +22,7 @@
 #include "select.h"
 #include "skinny.h"
 #include "skinny_train.h"
+#include "dgrad_rows.h"
 #include "wgrad2.h"
 
 using namespace sdrm;
@@ -55,6 +56,7 @@ struct Tuning {
   int wgrad_round = 1280;        // SDRM_WGRAD_ROUND: ... unless ONE round (this many work-groups) already gives eight slices or more
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
   int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
+  int dgrad_rows = 1;            // SDRM_DGRAD_ROWS: row-owned input gradients (csrc/dgrad_rows.h) behind the row-owned forward: 0 off
   int strips = 1;                // SDRM_WGRAD_STRIPS: strip-owned weight gradients (csrc/wgrad2.h) behind the row-owned forward: 0 off
   int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
                                  // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
@@ -71,6 +73,7 @@ struct sdrm_engine {
   // padded compute copies
   float *W0c = nullptr, *b0c = nullptr, *Whc = nullptr, *bhc = nullptr, *Woc = nullptr, *boc = nullptr;
   float *WhcT = nullptr, *WocT = nullptr;   // transposed copies [in][out]: dgrad is then an NT GEMM like the forwards
+  float *WhfT = nullptr, *WofT = nullptr;                 // the same of the transposes ([k = out][n = in]) for the row-owned dgrads
   float *W0f = nullptr, *Whf = nullptr, *Wof = nullptr;   // fragment-packed copies [WP/16][WP/16][64][4] for the row-owned forward
                                                           // (layer 0: the latent columns only); null when the net does not qualify
   bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
@@ -148,7 +151,7 @@ struct sdrm_engine {
 typedef sdrm_engine::SampleStateT SampleState;
 
 enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_SMP_L0, PC_SMP_HIDDEN,
-                 PC_SMP_OUT, PC_ROW_FWD, PC_WGRAD_STRIPS, PC_COUNT };
+                 PC_SMP_OUT, PC_ROW_FWD, PC_WGRAD_STRIPS, PC_DGRAD_ROWS, PC_COUNT };
 // the template arguments are <LOADA,LOADB,XFA,XFB,EPI> of gemm_kernel (what rocprofv3 prints after the tile type)
 static const char* kProfNames[PC_COUNT] = {
     "train: gemm_kernel<0,0,0,0,9> fwd layer0 (row-table bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
@@ -159,7 +162,8 @@ static const char* kProfNames[PC_COUNT] = {
     "sample: gemm_kernel<0,0,0,0,10> fwd layer0 (bias table, prelu epilogue)", "sample: gemm_kernel<0,0,0,0,10> fwd hidden (bias, prelu epilogue)",
     "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)",
     "train: k_row_fwd row-owned forward (staging + all layers + loss partial sums, one work-group per CU)",
-    "train: k_wgrad_strips weight gradients of all layers (strip-owned split-K, one work-group per CU)"};
+    "train: k_wgrad_strips weight gradients of all layers (strip-owned split-K, one work-group per CU)",
+    "train: k_dgrad_rows input gradient of one layer (row-owned, prelu' epilogue, one work-group per CU)"};
 
 namespace {
 
@@ -440,14 +444,14 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
   add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
   if (H >= 1) {
     add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
-    tab.j[n - 1].dstF = e->Whf;
+    tab.j[n - 1].dstF = e->Whf; tab.j[n - 1].dstFT = e->WhfT;
     if (bias_col >= 0) add(e->off_bh, W, 1, 1, 1, e->slabH + bias_col, e->WP, (size_t)e->WP * e->WP, H * SH, e->bhc, 1);
     else add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
     add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
         dgrad_blocks);
   }
   add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
-  tab.j[n - 1].dstF = e->Wof;
+  tab.j[n - 1].dstF = e->Wof; tab.j[n - 1].dstFT = e->WofT;
   if (bias_col >= 0) add(e->off_bo, L, 1, 1, 1, e->slabO + bias_col, e->WP, (size_t)e->LP * e->WP, SO, e->boc, 1);
   else add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
   tab.n_adam = n;
@@ -559,6 +563,46 @@ bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && 
 // Row-owned train forward (rowchain.h): one 96-row work-group per CU.  It replaces staging + H + 2 GEMM launches + the loss
 // partial sums when the batch fills whole rounds of the chip's 256 CUs (measured at B = 8192, L = 340: 169 us against
 // 182 + 18.7 + 11.7 us); a last round that leaves more than a sixth of the CUs idle loses to the per-layer path.
+// row-owned dgrads (dgrad_rows.h): the stacked rows are whole 96-row work-groups (the grouped order of the row-owned forward),
+// reduction axis == output axis == the padded width (LP == WP: L == W)
+bool use_dgrad_rows(const sdrm_engine* e, int MP) {
+  return e->cur_grouped && e->WhfT && e->tune.dgrad_rows > 0 && e->LP == e->WP && MP % RC_ROWS == 0 && e->WP >= 128 && e->WP <= 352;
+}
+
+template <int CT>
+int launch_dgrad_rows_ct(sdrm_engine* e, const DgradRowsArgs& a, int G, double flops, hipStream_t st) {
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_DGRAD_ROWS);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_DGRAD_ROWS);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  SDRM_LAUNCH(e, (k_dgrad_rows<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  return SDRM_OK;
+}
+
+// out[MP][WP] = (G[MP][WP] * W) * prelu'(pre), W given as the fragment-packed [k = out][n = in] copy
+int launch_dgrad_rows(sdrm_engine* e, const float* G, const float* WfT, const float* pre, const float* slope, float* out, float* partial,
+                      int MP, double flops, hipStream_t st) {
+  DgradRowsArgs a{};
+  a.G = G; a.ldg = e->WP; a.WfT = WfT; a.pre = pre; a.ldp = e->WP; a.slope = slope; a.out = out; a.ldo = e->WP; a.slope_part = partial;
+  const int Gn = MP / RC_ROWS;
+  switch (e->WP / 32) {
+    case 4: return launch_dgrad_rows_ct<4>(e, a, Gn, flops, st);
+    case 5: return launch_dgrad_rows_ct<5>(e, a, Gn, flops, st);
+    case 6: return launch_dgrad_rows_ct<6>(e, a, Gn, flops, st);
+    case 7: return launch_dgrad_rows_ct<7>(e, a, Gn, flops, st);
+    case 8: return launch_dgrad_rows_ct<8>(e, a, Gn, flops, st);
+    case 9: return launch_dgrad_rows_ct<9>(e, a, Gn, flops, st);
+    case 10: return launch_dgrad_rows_ct<10>(e, a, Gn, flops, st);
+    default: return launch_dgrad_rows_ct<11>(e, a, Gn, flops, st);
+  }
+}
+
 bool use_rowchain(const sdrm_engine* e, int B) {
   if (!e->W0f || e->tune.rowchain <= 0 || e->tune.force_cfg >= 0) return false;   // a forced tile means: the per-layer kernels
   if (e->tune.rowchain >= 2) return true;
@@ -785,6 +829,12 @@ int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int on) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.dgrad_rows = on ? 1 : 0;
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
   e->tune.skinny = on ? 1 : 0;
@@ -868,6 +918,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_DGRAD_ROWS")) e->tune.dgrad_rows = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
   e->LP = round_up(L, 32); e->WP = round_up(W, 32); e->TP = round_up(T + 1, 32); e->K0 = e->LP + e->TP;
   e->MPmax = round_up(RC_ROWS * ((max_rows + RC_USERS - 1) / RC_USERS), 128);   // either stacked row order fits
@@ -901,6 +952,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
                                                   // reference): the ones column round_up(W, 4) must be a pad column of U as well
     HIP_TRY(e, dalloc(&e->W0f, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->Whf, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->Wof, (size_t)e->WP * e->WP));
+    HIP_TRY(e, dalloc(&e->WhfT, (size_t)e->WP * e->WP)); HIP_TRY(e, dalloc(&e->WofT, (size_t)e->WP * e->WP));
     HIP_TRY(e, dalloc(&e->act, (size_t)(H + 1) * e->MPmax * e->WP));
     if (round_up(W, 4) < e->WP) e->ones_col = round_up(W, 4);
   }
@@ -957,7 +1009,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1187,6 +1239,22 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
                                       Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
     e->bwd_kc0 = kc0;
     e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = MP / 16;
+    e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+    return SDRM_OK;
+  }
+  if (use_dgrad_rows(e, MP)) {
+    // one work-group per 96 stacked rows and layer: one slope partial per work-group
+    int rc = launch_dgrad_rows(e, e->dY, e->WofT, pre_buf(e, H), slope_ptr(e, H), dpre_buf(e, H),
+                               e->alpha_part + (size_t)H * e->alpha_part_stride, MP, flO, st);
+    for (int k = H; k >= 1 && !rc; --k)
+      rc = launch_dgrad_rows(e, dpre_buf(e, k), e->WhfT, pre_buf(e, k - 1), slope_ptr(e, k - 1), dpre_buf(e, k - 1),
+                             e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, MP, flH, st);
+    if (rc) return rc;
+    if (with_wgrad0)
+      HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                      Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
+    e->bwd_kc0 = kc0;
+    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = MP / RC_ROWS;
     e->bwd_kcH = kcH; e->bwd_kcO = kcO;
     return SDRM_OK;
   }

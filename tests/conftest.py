@@ -44,9 +44,9 @@ def engine_cls():
                 if not self.rowchain_available:
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope")
-                # "row": the row-owned forward with the strip-owned weight gradients behind it (the default pairing);
-                # "row-tiles": the same forward with the batched 64x64-tile split-K launch
-                kw = dict(kw, tile=None, rowchain=2, wgrad_strips=kw["tile"] == "row")
+                # "row": the row-owned forward with the row-owned dgrads and the strip-owned weight gradients behind it (the
+                # default pairing); "row-tiles": the same forward with the 64x64-tile dgrad and batched split-K launches
+                kw = dict(kw, tile=None, rowchain=2, wgrad_strips=kw["tile"] == "row", dgrad_rows=kw["tile"] == "row")
             return super().debug_set(**kw)
 
     return TestEngine
