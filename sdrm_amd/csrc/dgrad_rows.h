@@ -30,21 +30,6 @@
 
 namespace sdrm {
 
-// Raw buffer loads: base in a 4-SGPR resource, a per-lane 32-bit offset, a scalar offset advanced on the scalar unit, an
-// immediate - ONE instruction and no VALU (the global_load form of rowchain.h costs a 64-bit VALU add per load, and with one
-// wave per SIMD a VALU instruction and the load waiting for it stall the MFMA stream: measured here, 32 cycles per load).
-// Out-of-range offsets return zero instead of faulting.
-typedef __amdgpu_buffer_rsrc_t brsrc;
-__device__ __forceinline__ brsrc make_brsrc(const void* p, uint32_t bytes) {   // p wave-uniform
-  const uint64_t v = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-__device__ __forceinline__ f32x4 bload4(brsrc r, uint32_t voff, uint32_t soff) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
-}
-
 struct DgradRowsArgs {
   const float* G; int ldg;      // incoming gradient [MP][ldg], columns [0, NP) are the reduction axis
   const float* WfT;             // fragment-packed [NP/16][NP/16][64][4]: element (n = in, k = out), wfrag_index(n, k, NP / 16)
@@ -86,8 +71,8 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
     const int s = (e * CT + ct) * 3 + rt;
     // swapped operands: the tile comes out transposed.  Written as asm with the accumulator tied in place: through the builtin
     // the register allocator renames accumulators in the last K-step of the loop body and copies them back at its top
-    // (~250 v_accvgpr_mov per trip).  The price: the compiler's hazard recogniser does not see an MFMA here: dr_begin /
-    // dr_settle guard the two places where compiler-made VALU code meets the accumulators (their zeros, their first read);
+    // (~250 v_accvgpr_mov per trip).  The price: the compiler's hazard recogniser does not see an MFMA here: rc_acc_begin /
+    // rc_acc_settle (rowchain.h) guard the two places where compiler-made VALU code meets the accumulators (their zeros, their first read);
     // tests/test_isa_lint.py checks the generated code for any other
     if (DR_DIAG & 4) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bu[ct][e]), "v"(au[rt][e]));
     else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bu[ct][e]), "v"(au[rt][e]));
@@ -131,30 +116,6 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
                                             poff);
     dr_peel<CT, KS, PEEL, J + 1>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
   }
-}
-
-// before the first dr_kstep: every accumulator's zero is materialised in ITS register here (an opaque read-modify of each: the
-// compiler can no longer write the constant lazily, right in front of the first asm MFMA that reads it), then the wait states
-// a VALU write needs before an MFMA may read it
-template <int CT>
-__device__ __forceinline__ void dr_begin(f32x4 (&acc)[3][CT]) {
-#pragma unroll
-  for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
-  asm volatile("s_nop 7");
-}
-
-// after the last dr_kstep: the wait states an MFMA result needs before a VALU instruction may read it (the asm MFMAs are opaque to
-// the compiler), as a dependence of every accumulator: volatile asm statements keep their order, so every read follows the s_nops
-template <int CT>
-__device__ __forceinline__ void dr_settle(f32x4 (&acc)[3][CT]) {
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]));
-#pragma unroll
-  for (int rt = 0; rt < 3; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-      if (rt + ct > 0) asm volatile("" : "+a"(acc[rt][ct]));
 }
 
 template <int CT>
@@ -206,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs 
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) B[0][ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
 
-  dr_begin<CT>(acc);
+  rc_acc_begin<CT>(acc);
   DR_STAMP(1);
   constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;   // bytes of one K-step of the fragment-packed weights
   // main loop: four K-steps per trip (the G sets rotate with period four, the W sets with period two); the last PEEL K-steps
@@ -222,7 +183,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs 
   DR_STAMP(2);
   dr_peel<CT, KS, PEEL, 0>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
   DR_STAMP(3);
-  dr_settle<CT>(acc);
+  rc_acc_settle<CT>(acc);
   // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
   float part4[4] = {0.f, 0.f, 0.f, 0.f};   // four chains: one wave per SIMD, nothing else hides a dependent FMA's latency
 #pragma unroll

@@ -4,13 +4,17 @@
 // Ownership: ONE work-group per CU owns 96 stacked rows - the P, S and Q rows of 32 users (train_SDRM.py:331-333: the three
 // forwards of a train step) - through staging (q_sample + three dropout masks, :326-331 / :100) and ALL H+2 layers (:97-103).
 //   * the 96 x NP activation tile lives in LDS (135 KB at NP = 352) and is overwritten in place after each layer's barrier;
-//     it holds the layer INPUT as it is stored for the backward (dropped-out latents for layer 0, pre-activations above:
-//     PReLU is applied when a fragment is read), so the same tile is streamed out to HBM - U, pre[k], coalesced 16-byte
-//     stores - a few rows per K-step while the next layer multiplies out of it: no store burst, no separate staging launch;
+//     it holds the layer INPUT exactly as the MFMAs want it and as the weight gradients read it later (dropped-out latents
+//     for layer 0, ACTIVATIONS above: PReLU is applied ONCE per element, in the epilogue that writes the tile), so the same
+//     tile is streamed out to HBM - U, act[k], coalesced 16-byte stores - a few rows per K-step while the next layer
+//     multiplies out of it; the pre-activations the dgrads want go to HBM straight from the accumulators (the MFMA operands
+//     are swapped, the tile comes out transposed: a lane holds four consecutive COLUMNS of one row, a 16-byte store);
 //   * the weights never touch LDS: every wave fetches its MFMA B fragments straight from L2 out of a FRAGMENT-PACKED copy
 //     ([k-step][column tile][lane][4 floats]: one contiguous 1 KiB wave-load per 16x16 tile and 16-deep K-step; k_adam
 //     writes these copies beside the padded ones), double-buffered in registers one whole K-step (132 MFMAs = 4224 cycles)
-//     ahead: an L2 round trip is a tenth of that;
+//     ahead, by raw buffer loads (resource + lane offset + scalar offset: no VALU address arithmetic);
+//   * NO VALU instruction in a K-step except the LDS address of the two stream chunks: fp32 MFMA runs on the vector lanes,
+//     a VALU instruction beside it is paid in full (tools/mfma_shadow_asm_probe.py), memory instructions are not;
 //   * 4 waves, one per SIMD, as 2 x 2: a wave owns 3 row tiles x CT column tiles of v_mfma_f32_16x16x4_f32 (33 accumulator
 //     quads at NP = 352) - per K-step 3 ds_read_b128 + CT global loads feed 12 * CT MFMAs, and the only barriers are the two
 //     around each layer's in-place epilogue (the per-layer path pays one per 8 MFMAs and a launch ramp + tail per layer);
@@ -82,26 +86,23 @@ struct RowChainCfg {
 };
 
 // one K-step of a wave: 12 * CT MFMAs out of (ac, bc); in their shadows the next step's B fragments (global) and A fragments
-// (LDS, PReLU on read) land in (an, bn), and two chunks of the activation tile are streamed LDS -> HBM
+// (LDS) land in (an, bn), and two chunks of the activation tile are streamed LDS -> HBM
 // diagnostic builds only (-DRC_DIAG=mask): drop a piece of the main loop to see what it costs - bit0 the tile stream, bit1 the B
-// fragment loads, bit2 the A fragment reads, bit3 PReLU on read
+// fragment loads, bit2 the A fragment reads
 #ifndef RC_DIAG
 #define RC_DIAG 0
 #endif
+#ifndef RC_PIECE_STRIDE   // MFMAs between two pipeline pieces of a K-step (the pieces sit at its front)
+#define RC_PIECE_STRIDE 3
+#endif
 
 // fp32 MFMA runs on the SIMD's fp32 vector lanes (that is why its peak equals the vector peak): a VALU instruction of the same
-// wave is NOT hidden behind it - measured (tools/mfma_filler_probe.hip, one wave per SIMD): a group of n plain VALU
-// instructions between two v_mfma_f32_16x16x4_f32 costs ~6 + 2.2 n cycles of a 32-cycle MFMA slot, LDS reads and global loads
-// cost nothing.  So the main loop is written for FEW VALU instructions, in FEW groups: B loads and tile-stream stores address
-// through scalar bases (advanced on the scalar unit) + a constant lane offset, and PReLU on read is two instructions per value.
+// wave is NOT hidden behind it (tools/mfma_filler_probe.hip, tools/mfma_shadow_asm_probe.py: 4 - 9 cycles each), LDS reads,
+// global loads and stores cost nothing - unless their ADDRESS is a VALU result of the same K-step: the in-order wave then
+// stalls for the add and for the load that waits for it (~32 cycles per load, csrc/dgrad_rows.h).  So the K-step has no VALU
+// work: weights by raw buffer loads (scalar offsets), the tile stream by buffer stores, PReLU in the epilogue.
 //
-// PReLU for a slope in [0, 1] (the initial 0.25 and every trained value seen): max(v, slope * v).  The generic form
-// (max(v, 0) + slope * min(v, 0), three instructions) is taken when the slope is outside that range (wave-uniform choice).
-__device__ __forceinline__ float prelu_01(float v, float slope) {
-  float r;
-  asm("v_mul_f32 %0, %1, %2\n\tv_max_f32 %0, %0, %1" : "=&v"(r) : "v"(v), "v"(slope));
-  return r;
-}
+// PReLU, the generic form: max(v, 0) + slope * min(v, 0), three instructions without a compare.
 __device__ __forceinline__ float prelu_any(float v, float slope) {
   float lo, r;
   asm("v_min_f32 %0, 0, %2\n\tv_max_f32 %1, 0, %2\n\tv_fmac_f32 %1, %3, %0" : "=&v"(lo), "=&v"(r) : "v"(v), "v"(slope));
@@ -124,56 +125,91 @@ __device__ __forceinline__ void gstore4(gchar* base, uint32_t off, float4 v) {
   f32x4 w = {v.x, v.y, v.z, v.w};
   *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(base + off) = w;
 }
-// the same with the non-temporal hint: bytes nobody reads before the weight gradients, a whole backward chain later (U, the
-// activations) - they should not push the pre-activations and Y, which the loss seeds and the dgrads read next, out of the caches
-__device__ __forceinline__ void gstore4_nt(gchar* base, uint32_t off, float4 v) {
-  f32x4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(base + off));
+
+// Raw buffer accesses: base in a 4-SGPR resource, a per-lane 32-bit offset, a scalar offset advanced on the scalar unit -
+// ONE instruction and no VALU (the global_load form costs a 64-bit VALU add per access once the base moves).  Loads beyond the
+// resource's size return zero, stores beyond it are dropped.
+typedef __amdgpu_buffer_rsrc_t brsrc;
+__device__ __forceinline__ brsrc make_brsrc(const void* p, uint32_t bytes) {   // p wave-uniform
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 bload4(brsrc r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+// NT: the non-temporal hint - bytes nobody reads before the weight gradients, a whole backward chain later (U, the activations):
+// they should not push the pre-activations and Y, which the loss seeds and the dgrads read next, out of the caches
+template <bool NT>
+__device__ __forceinline__ void bstore4(brsrc r, uint32_t voff, uint32_t soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), r, (int)voff, (int)soff, NT ? 2 : 0);
 }
 
-// position of a thread in the sweep of the activation tile (one float4 per thread and chunk): chunk j covers the flat quad
-// indices j * 256 + tid, row = f / QP, quad = f % QP; stepping a chunk adds 256 = (256 / QP) rows + (256 % QP) quads, with one
-// wrap at most - branch-free: the K-step must stay ONE basic block (see rc_kstep)
-template <int QP, int LDA>
-struct RcSweep {
-  static constexpr int DR = NTHREADS / QP, DQ = NTHREADS % QP;
-  int cq; uint32_t lds_off, g_off;   // quad in its row; byte offsets of the quad in the LDS tile / in the HBM rows
-  uint32_t gd0, gd1;                 // HBM byte step of a chunk without / with a row wrap
+// The sweep of the activation tile (LDS -> HBM, one float4 per thread and chunk): thread -> (row tid / 8, quad tid % 8) of a
+// 32-row x 8-quad block, chunk c = block (c / CT, c % CT) - every chunk is the same lane pattern at a UNIFORM offset, so the
+// stepping lives on the scalar unit (and it is the pattern the staging writes the tile in)
+struct RcStream {
+  uint32_t lds0, g0;     // this lane's byte offsets in chunk 0: LDS tile / HBM rows
+  uint32_t sl, sg;       // uniform byte offsets of the current chunk
+  int jj;                // its column block
+  uint32_t gwrap;        // HBM step from the last column block of a row block to the first of the next
+  template <int CT, int LDA>
   __device__ __forceinline__ void init(int tid, int sld) {
-    const int row = tid / QP;
-    cq = tid - row * QP;
-    lds_off = (uint32_t)(row * LDA + 4 * cq) * 4u;
-    g_off = (uint32_t)(row * sld + 4 * cq) * 4u;
-    gd0 = (uint32_t)((DR * sld + 4 * DQ) * 4);
-    gd1 = (uint32_t)(((DR + 1) * sld + 4 * (DQ - QP)) * 4);
+    lds0 = (uint32_t)(((tid >> 3) * LDA + 4 * (tid & 7)) * 4);
+    g0 = (uint32_t)(((tid >> 3) * sld + 4 * (tid & 7)) * 4);
+    sl = 0u; sg = 0u; jj = 0;
+    gwrap = (uint32_t)(RC_USERS * sld * 4 - (CT - 1) * 128);
   }
+  template <int CT, int LDA>
   __device__ __forceinline__ void next() {
-    const bool wrap = cq >= QP - DQ;
-    cq += wrap ? DQ - QP : DQ;
-    lds_off += wrap ? (uint32_t)(((DR + 1) * LDA + 4 * (DQ - QP)) * 4) : (uint32_t)((DR * LDA + 4 * DQ) * 4);
-    g_off += wrap ? gd1 : gd0;
+    const bool wrap = jj == CT - 1;
+    jj = wrap ? 0 : jj + 1;
+    sl += wrap ? (uint32_t)(RC_USERS * LDA * 4 - (CT - 1) * 128) : 128u;
+    sg += wrap ? gwrap : 128u;
   }
 };
 
+// before the first K-step of a layer: every accumulator's initial value is materialised in ITS register here (an opaque
+// read-modify of each: the compiler can no longer write it lazily, right in front of the first asm MFMA that reads it), then the
+// wait states a VALU write needs before an MFMA may read it
+template <int CT>
+__device__ __forceinline__ void rc_acc_begin(f32x4 (&acc)[3][CT]) {
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+a"(acc[rt][ct]));
+  asm volatile("s_nop 7");
+}
+// after the last K-step: the wait states an MFMA result needs before a VALU instruction may read it, as a dependence of every
+// accumulator: volatile asm statements keep their order, so every read follows the s_nops
+template <int CT>
+__device__ __forceinline__ void rc_acc_settle(f32x4 (&acc)[3][CT]) {
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][0]));
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      if (rt + ct > 0) asm volatile("" : "+a"(acc[rt][ct]));
+}
+
 // One K-step of a wave: 12 * CT MFMAs out of (ac, bc), and between them the pieces that prepare the next step: its B fragments
-// (global, CT wave-loads of 1 KiB), its A fragments (3 ds_read_b128) with their PReLU as ONE group of VALU instructions, and
-// NS chunks of the tile stream LDS -> HBM.  The body must stay ONE basic block with every piece where it is written: a
-// branch inside it, or a load the compiler is free to hoist (loads of read-only memory are not ordered against sched_barrier),
-// and all pieces end up in front of the MFMAs.  Hence compile-time piece counts, and every load's offset is passed through an
-// empty asm volatile at its slot, which pins it there.
-// ACT: the streamed tile holds pre-activations and their ACTIVATIONS go to `adst` as well (same offsets): the weight gradients
-// then read their operand as it is - PReLU on operand load costs the split-K kernel a tenth of its time, here it is 12 VALU
-// instructions per chunk.
-template <int CT, int LDA, int NS, bool ACT>
+// (CT raw buffer wave-loads of 1 KiB), its A fragments (3 ds_read_b128) and NS chunks of the tile stream LDS -> HBM (read, then
+// NS pieces later the store).  The body must stay ONE basic block with every piece where it is written: a branch inside it, or a
+// load the compiler is free to hoist (loads of read-only memory are not ordered against sched_barrier), and all pieces end up in
+// front of the MFMAs.  Hence compile-time piece counts, and every access's offset is passed through an empty asm volatile at its
+// slot, which pins it there.  STREAM = false: the tile is not stored (a layer whose input nobody reads again).
+// The MFMA operands are SWAPPED (weights as srcA, activations as srcB): the 16 x 16 tile comes out transposed, lane (li, lq)
+// holds row li, columns 4 lq .. 4 lq + 3 of it - every epilogue access is a 16-byte one.
+template <int CT, int LDA, int NS, bool STREAM, bool NT>
 __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], const f32x4 (&bc)[CT], f32x4 (&an)[3],
-                                         f32x4 (&bn)[CT], const gchar* wnext, uint32_t lane16, uint32_t anext, float slope,
-                                         const float* __restrict__ Act, gchar* sdst, gchar* adst, RcSweep<8 * CT, LDA>& sw) {
+                                         f32x4 (&bn)[CT], brsrc wres, uint32_t wnext, uint32_t lane16, uint32_t anext,
+                                         const float* __restrict__ Act, brsrc sres, RcStream& sw) {
   constexpr int NSLOT = 12 * CT;
-  constexpr int NPH = ACT ? 3 : 2;   // phases of a chunk: LDS read, store, (activation store)
-  constexpr int P_A = CT, P_S = CT + 3, P_X = P_S + NPH * NS, NPIECE = P_X + 1;
-  constexpr int STRIDE = NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1;
+  constexpr int P_A = CT, P_S = CT + 3, NPIECE = P_S + (STREAM ? 2 * NS : 0);
+  constexpr int STRIDE = NSLOT / NPIECE >= RC_PIECE_STRIDE ? RC_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1);
   static_assert(NPIECE <= NSLOT && NS <= 2, "not enough MFMA slots for the pipeline pieces");
-  float4 sv0 = make_float4(0.f, 0.f, 0.f, 0.f), sv1 = sv0;
+  f32x4 sv0 = {0.f, 0.f, 0.f, 0.f}, sv1 = sv0;
   uint32_t so0 = 0, so1 = 0;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -182,15 +218,18 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
     const int s = (e * CT + ct) * 3 + rt;
-    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[rt][e], bc[ct][e], acc[rt][ct], 0, 0, 0);
+    // asm with the accumulator tied in place: through the builtin the register allocator renames accumulators inside the loop
+    // body and copies them back (v_accvgpr_mov by the hundred).  The price: the compiler's hazard recogniser does not see an
+    // MFMA here - rc_acc_begin / rc_acc_settle guard the two places where compiler-made VALU code meets the accumulators
+    // (their initial values, their first read); tests/test_isa_lint.py checks the generated code for any other
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bc[ct][e]), "v"(ac[rt][e]));
     if (s % STRIDE == 0 && s / STRIDE < NPIECE) {
       const int p = s / STRIDE;
       if (p < P_A) {
         if (!(RC_DIAG & 2)) {
-          // a scalar base per 4 KiB (the immediate offset field covers the rest), opaque at this slot: pins the load here
-          const gchar* wb = wnext + (p / 4) * 4096;
-          asm volatile("" : "+s"(wb));
-          bn[p] = gload4(wb + (p % 4) * 1024, lane16);
+          uint32_t so = wnext + (p / 4) * 4096;   // opaque at this slot: pins the load here
+          asm volatile("" : "+s"(so));
+          bn[p] = bload4(wres, lane16 + (p % 4) * 1024, so);
         }
       } else if (p < P_S) {
         if (!(RC_DIAG & 4)) {
@@ -198,31 +237,21 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
           asm volatile("" : "+v"(ao));
           an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
         }
-      } else if (p < P_X) {
-        // tile stream, chunk q: LDS read, then (NS pieces later) the HBM store and the step to the next chunk
+      } else {
+        // tile stream, chunk q: LDS read, then (NS pieces later) the HBM store
         const int k = p - P_S, ph = k / NS, q = k % NS;
         if (!(RC_DIAG & 1)) {
-          float4& v = q == 0 ? sv0 : sv1;
+          f32x4& v = q == 0 ? sv0 : sv1;
           uint32_t& so = q == 0 ? so0 : so1;
           if (ph == 0) {
-            uint32_t lo = sw.lds_off;
+            uint32_t lo = sw.lds0 + sw.sl;
             asm volatile("" : "+v"(lo));
-            v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(Act) + lo);
-            so = sw.g_off;
-            sw.next();
-          } else if (ph == 1) {
-            if (ACT) gstore4(sdst, so, v);   // pre-activations: read again by the first dgrad
-            else gstore4_nt(sdst, so, v);    // U: read again by the layer-0 weight gradient only
+            v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + lo);
+            so = sw.sg;
+            sw.template next<CT, LDA>();
           } else {
-            gstore4_nt(adst, so, make_float4(prelu_any(v.x, slope), prelu_any(v.y, slope), prelu_any(v.z, slope), prelu_any(v.w, slope)));
-          }
-        }
-      } else {
-        if (!(RC_DIAG & 8)) {
-#pragma unroll
-          for (int f = 0; f < 3; ++f) {
-            an[f].x = prelu_any(an[f].x, slope); an[f].y = prelu_any(an[f].y, slope);
-            an[f].z = prelu_any(an[f].z, slope); an[f].w = prelu_any(an[f].w, slope);
+            asm volatile("" : "+s"(so));
+            bstore4<NT>(sres, sw.g0, so, v);
           }
         }
       }
@@ -368,117 +397,116 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   RC_STAMP(1);
 
   // ---------------------------------------------------------------- layers
-  // wave (wr, wc): row tile rt = pass rt of users 16 wr .. 16 wr + 15 (tile rows 32 rt + 16 wr ..), column tiles CT wc ..
-  const float* abase = Act + (16 * wr + li) * LDA + 4 * lq;     // + 32 * rt * LDA + 16 * ks
+  // wave (wr, wc): row tile rt = pass rt of users 16 wr .. 16 wr + 15 (tile rows 32 rt + 16 wr ..), column tiles CT wc ..;
+  // lane (li, lq) holds of tile (rt, ct) row 32 rt + 16 wr + li, columns 16 (CT wc + ct) + 4 lq .. + 3 (the transposed MFMA tile)
+  const float* abase = Act + (16 * wr + li) * LDA + 4 * lq;     // + 32 * rt * LDA + 16 * ks: A fragment reads
   const uint32_t aoff = (uint32_t)(((16 * wr + li) * LDA + 4 * lq) * 4);   // the same as a byte offset into the tile
-  const uint32_t lane16 = 16u * (uint32_t)lane;   // byte offset of a lane's float4 in a 1 KiB wave-load / wave-store
-  const int myusr = u0 + 16 * wr + 4 * lq;                      // + r: the user of accumulator register r (every rt, ct)
+  const uint32_t lane16 = 16u * (uint32_t)lane;   // byte offset of a lane's float4 in a 1 KiB wave-load
+  const int myrow = 16 * wr + li;                 // + 32 rt: the lane's row of the tile; its user is u0 + myrow
+  const int mycol = 16 * CT * wc + 4 * lq;        // + 16 ct: the first of its four columns
+  float* __restrict__ otile = Act + myrow * LDA + mycol;   // + 32 rt * LDA + 16 ct: the lane's quad of the tile
   f32x4 acc[RT][CT];
   f32x4 b0[CT], b1[CT];
   f32x4 a0[RT], a1[RT];
-  float xq[CT][4];   // x0 at this lane's accumulator positions (loss sums), requested before the out layer's loop
+  f32x4 xq[CT];   // x0 at this lane's accumulator positions (loss sums), requested before the out layer's loop
 
   const int nlayers = a.H + 2;
   for (int layer = 0; layer < nlayers; ++layer) {
     const bool last = layer == nlayers - 1;
-    const gchar* Wf = uniform_gptr((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)(CT * wc) * 256);
-    // PReLU on fragment read; layer 0's input is not a pre-activation: slope 1 leaves it as it is, bit for bit
-    const float slope = layer == 0 ? 1.f : (layer == 1 ? *a.slope0 : *a.slopeh);
-    // this layer streams its own input tile out to HBM while it multiplies: U (layer 0) or pre[layer - 1]
-    float* __restrict__ sdst = layer == 0 ? a.U + grow0 * a.K0 : a.pre + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp;
+    const brsrc Wf = make_brsrc((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)(CT * wc) * 256, (uint32_t)((KS * NCT - CT * wc) * 1024));
+    // this layer streams its own input tile out to HBM while it multiplies: U (layer 0) or the activations act[layer - 1]
+    // (nobody reads them when the weight gradients take PReLU(pre) themselves: a.act == null)
+    const bool stream = layer == 0 || a.act != nullptr;
+    float* sdst = layer == 0 ? a.U + grow0 * a.K0 : a.act + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp;
     const int sld = layer == 0 ? a.K0 : a.ldp;
+    const brsrc sres = make_brsrc(stream ? sdst : a.U, stream ? (uint32_t)(RC_ROWS * sld * 4) : 0u);
 
     // accumulators start at the bias (layer 0: the row's own row of b0 + C0[t])
-    if (layer == 0) {
-      int tr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tr[r] = trow[16 * wr + 4 * lq + r];
+    {
+      const float* bsrc = layer == 0 ? a.B0tab + (size_t)trow[myrow] * a.ldtab : (last ? a.bo : a.bh);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int col = 16 * (CT * wc + ct) + li;
+        const float4 bv = *reinterpret_cast<const float4*>(bsrc + mycol + 16 * ct);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float bv = a.B0tab[(size_t)tr[r] * a.ldtab + col];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt][ct][r] = bv;
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const float bv = (last ? a.bo : a.bh)[16 * (CT * wc + ct) + li];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[rt][ct][r] = bv;
+        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = f32x4{bv.x, bv.y, bv.z, bv.w};
       }
     }
     if (last) {
+      const int usr = u0 + myrow;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const int col = 16 * (CT * wc + ct) + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xq[ct][r] = (myusr + r < a.B && col < a.L) ? a.x0[(size_t)(myusr + r) * a.L + col] : 0.f;
+        const int col = mycol + 16 * ct;
+        const float4 x = (usr < a.B && col < a.L) ? load4_unpadded(a.x0, usr, col, a.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xq[ct] = f32x4{x.x, x.y, x.z, x.w};
       }
     }
     // prologue: K-step 0's fragments
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) b0[ct] = gload4(Wf, lane16 + ct * 1024u);
+    for (int ct = 0; ct < CT; ++ct) b0[ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      a0[rt] = *reinterpret_cast<const f32x4*>(abase + rt * RC_USERS * LDA);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a0[rt][k] = prelu_any(a0[rt][k], slope);
-    }
+    for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const f32x4*>(abase + rt * RC_USERS * LDA);
     // the tile stream: 3 CT chunks over the CT pairs of K-steps (two chunks, then one)
-    gchar* sdw = uniform_gptr(sdst);
-    gchar* adw = uniform_gptr(layer == 0 ? nullptr : a.act + (size_t)(layer - 1) * a.pre_stride + grow0 * a.ldp);
-    RcSweep<QP, LDA> sw;
-    sw.init(tid, sld);
-    auto kloop = [&](auto act_tag) {
-      constexpr bool ACT = decltype(act_tag)::value;
-      for (int ks = 0; ks < KS; ks += 2) {
-        const int k2 = ks + 2 < KS ? ks + 2 : ks;   // past the end: a harmless re-read
-        rc_kstep<CT, LDA, 2, ACT>(acc, a0, b0, a1, b1, Wf + (size_t)(ks + 1) * (NCT * 1024), lane16, aoff + 64u * (ks + 1), slope, Act, sdw, adw, sw);
-        rc_kstep<CT, LDA, 1, ACT>(acc, a1, b1, a0, b0, Wf + (size_t)k2 * (NCT * 1024), lane16, aoff + 64u * k2, slope, Act, sdw, adw, sw);
+    RcStream sw;
+    sw.template init<CT, LDA>(tid, sld);
+    auto kloop = [&](auto stream_tag, auto nt_tag) {
+      constexpr bool STREAM = decltype(stream_tag)::value, NT = decltype(nt_tag)::value;
+      for (uint32_t ks = 0; ks < (uint32_t)KS; ks += 2) {
+        const uint32_t k2 = ks + 2 < (uint32_t)KS ? ks + 2 : ks;   // past the end: a harmless re-read
+        rc_kstep<CT, LDA, 2, STREAM, NT>(acc, a0, b0, a1, b1, Wf, (ks + 1) * (uint32_t)(NCT * 1024), lane16, aoff + 64u * (ks + 1), Act, sres, sw);
+        rc_kstep<CT, LDA, 1, STREAM, NT>(acc, a1, b1, a0, b0, Wf, k2 * (uint32_t)(NCT * 1024), lane16, aoff + 64u * k2, Act, sres, sw);
       }
     };
-    if (layer == 0 || a.act == nullptr) kloop(std::false_type{});
-    else kloop(std::true_type{});
+    rc_acc_begin<CT>(acc);
+    if (stream) kloop(std::true_type{}, std::true_type{});
+    else kloop(std::false_type{}, std::false_type{});
+    rc_acc_settle<CT>(acc);
     if (layer < 3) RC_STAMP(2 + 3 * layer);
     if (last) break;
 
-    // in-place epilogue: every wave is done reading the tile, then it takes this layer's outputs (pre-activations)
+    // in-place epilogue: every wave is done reading the tile; then the pre-activations go to HBM as they are (read next by the
+    // dgrads) and their PReLU into the tile - the next layer's input, and what the stream stores for the weight gradients
     __syncthreads();
     if (layer < 3) RC_STAMP(3 + 3 * layer);
-    float* __restrict__ obase = Act + (16 * wr + 4 * lq) * LDA + 16 * CT * wc + li;   // + (32 * rt + r) * LDA + 16 * ct
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    {
+      const float slope = layer == 0 ? *a.slope0 : *a.slopeh;
+      gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
+      const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);
+      const uint32_t prt = (uint32_t)(RC_USERS * a.ldp * 4);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) obase[(RC_USERS * rt + r) * LDA + 16 * ct] = acc[rt][ct][r];
+        for (int ct = 0; ct < CT; ++ct) {
+          const f32x4 v = acc[rt][ct];
+          gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+          *reinterpret_cast<float4*>(otile + rt * RC_USERS * LDA + 16 * ct) =
+              make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
+        }
+    }
     __syncthreads();
     if (layer < 3) RC_STAMP(4 + 3 * layer);
   }
 
   // ---------------------------------------------------------------- out layer: tanh, Y, loss partial sums (:196-198), from registers
-  float* __restrict__ ydst = a.Y + (grow0 + 16 * wr + 4 * lq) * a.ldy + 16 * CT * wc + li;   // + (32 * rt + r) * ldy + 16 * ct
+  gchar* yw = uniform_gptr(a.Y + grow0 * a.ldy);
+  const uint32_t ybase = (uint32_t)((myrow * a.ldy + mycol) * 4), yrt = (uint32_t)(RC_USERS * a.ldy * 4);
+  const bool uok = u0 + myrow < a.B;
   double sD = 0, sC = 0, sR = 0, sR2 = 0;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    const int col = 16 * (CT * wc + ct) + li;
+    const int col = mycol + 16 * ct;
     float fD = 0.f, fC = 0.f, fR = 0.f, fR2 = 0.f;
+    float P[4], S[4], Q[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float P = tanh_fast(acc[0][ct][r]), S = tanh_fast(acc[1][ct][r]), Q = tanh_fast(acc[2][ct][r]);
-      ydst[(size_t)r * a.ldy + 16 * ct] = P;
-      ydst[(size_t)(RC_USERS + r) * a.ldy + 16 * ct] = S;
-      ydst[(size_t)(2 * RC_USERS + r) * a.ldy + 16 * ct] = Q;
-      if (myusr + r < a.B && col < a.L) {
-        const float R = P - xq[ct][r];
-        const float D = (Q - S) * (1.f / MU2) - R;   // a multiply: an IEEE division is ten instructions, 132 times per lane
-        const float RS = R - S;
+    for (int i = 0; i < 4; ++i) { P[i] = tanh_fast(acc[0][ct][i]); S[i] = tanh_fast(acc[1][ct][i]); Q[i] = tanh_fast(acc[2][ct][i]); }
+    gstore4(yw + ct * 64, ybase, make_float4(P[0], P[1], P[2], P[3]));
+    gstore4(yw + ct * 64, ybase + yrt, make_float4(S[0], S[1], S[2], S[3]));
+    gstore4(yw + ct * 64, ybase + 2 * yrt, make_float4(Q[0], Q[1], Q[2], Q[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (uok && col + i < a.L) {
+        const float R = P[i] - xq[ct][i];
+        const float D = (Q[i] - S[i]) * (1.f / MU2) - R;   // a multiply: an IEEE division is ten instructions, 132 times per lane
+        const float RS = R - S[i];
         fD += D * D; fC += RS * RS; fR += R; fR2 += R * R;
       }
     }
