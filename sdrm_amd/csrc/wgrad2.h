@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bufres.h"
 #include "gemm.h"
 
 // diagnostic builds only (-DWG2_DIAG=mask): bit0 no MFMAs / fragment reads, bit1 no LDS stores in the loop, bit2 no global loads in the loop
@@ -98,15 +99,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_wgrad_strips(const Wg2Args a) {
   // ---- staging assignment: A tiles row-major [16][WP] as float4, thread f -> (row f / (WP/4), quad f % (WP/4))
   constexpr int QA = WP / 4;
   const Wg2Problem Pa = wg2_problem(a, pa), Pb = wg2_problem(a, pb);
-  const float* Aa = Pa.A; const int lda_a = Pa.lda;
-  const float* Ab = Pb.A; const int lda_b = Pb.lda;
+  // operands through raw buffer resources (bufres.h): per-lane offsets fixed for the whole launch, the row block as a SCALAR
+  // offset - a global_load's 64-bit address would be two VALU instructions per load, and with one wave per SIMD a VALU
+  // instruction and the load that waits for it stall the MFMA stream (csrc/dgrad_rows.h)
+  const int lda_a = Pa.lda, lda_b = Pb.lda;
+  const brsrc Ra = make_brsrc(Pa.A, (uint32_t)a.rows * (uint32_t)lda_a * 4u), Rb = make_brsrc(Pb.A, (uint32_t)a.rows * (uint32_t)lda_b * 4u);
   // the B block this thread stages for j = 0, 1: strip (wave >> 1) + 2 j of the unit (idle strips repeat the first problem)
-  const float* Bsrc[2]; int Bld[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const Wg2Strip ss = a.strip[unit][(wave >> 1) + 2 * j];
-    const Wg2Problem Ps = wg2_problem(a, ss.problem < 0 ? pa : ss.problem);
-    Bsrc[j] = Ps.B + 32 * (ss.problem < 0 ? 0 : ss.ktile); Bld[j] = Ps.ldb;
+  brsrc RB0, RB1; int Bld[2];
+  {
+    const Wg2Strip s0 = a.strip[unit][(wave >> 1)], s1 = a.strip[unit][(wave >> 1) + 2];
+    const Wg2Problem P0 = wg2_problem(a, s0.problem < 0 ? pa : s0.problem), P1 = wg2_problem(a, s1.problem < 0 ? pa : s1.problem);
+    Bld[0] = P0.ldb; Bld[1] = P1.ldb;
+    const int c0 = 32 * (s0.problem < 0 ? 0 : s0.ktile), c1 = 32 * (s1.problem < 0 ? 0 : s1.ktile);
+    RB0 = make_brsrc(P0.B + c0, ((uint32_t)a.rows * (uint32_t)P0.ldb - (uint32_t)c0) * 4u);
+    RB1 = make_brsrc(P1.B + c1, ((uint32_t)a.rows * (uint32_t)P1.ldb - (uint32_t)c1) * 4u);
   }
   // Operands stream from HBM and one work-group per CU has few loads in flight: the loads of a K-step are requested THREE steps
   // before they are stored to LDS (three register sets in rotation).  With one wave per SIMD every memory instruction's issue time
@@ -131,12 +137,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_wgrad_strips(const Wg2Args a) {
     rowA[j] = f / QA; quadA[j] = f - rowA[j] * QA;
   }
   const int rowB = (tid & 127) >> 3, quadB = tid & 7;
+  uint32_t voA[C::NLA], voA2[C::NLA], voB[2];   // byte offsets of this thread's pieces inside a 16-row block
+#pragma unroll
+  for (int j = 0; j < C::NLA; ++j) {
+    voA[j] = (uint32_t)((rowA[j] * lda_a + 4 * quadA[j]) * 4);
+    voA2[j] = (uint32_t)((rowA[j] * lda_b + 4 * quadA[j]) * 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) voB[j] = (uint32_t)((rowB * Bld[j] + 4 * quadB) * 4);
+  auto as4 = [](f32x4_b v) __attribute__((always_inline)) { return make_float4(v[0], v[1], v[2], v[3]); };
   auto gload_piece = [&](auto two_tag, RSet& r, int m0, int k) __attribute__((always_inline)) {
     constexpr bool TWO = decltype(two_tag)::value;
     constexpr int NA = TWO ? 2 * C::NLA : C::NLA;
-    if (k < C::NLA) r.a[k] = *reinterpret_cast<const float4*>(Aa + (size_t)(m0 + rowA[k]) * lda_a + 4 * quadA[k]);
-    else if (TWO && k < NA) r.a2[k - C::NLA] = *reinterpret_cast<const float4*>(Ab + (size_t)(m0 + rowA[k - C::NLA]) * lda_b + 4 * quadA[k - C::NLA]);
-    else if (k < NA + C::NLB) r.b[k - NA] = *reinterpret_cast<const float4*>(Bsrc[k - NA] + (size_t)(m0 + rowB) * Bld[k - NA] + 4 * quadB);
+    if (k < C::NLA) r.a[k] = as4(bload4(Ra, voA[k], (uint32_t)(m0 * lda_a) * 4u));
+    else if (TWO && k < NA) r.a2[k - C::NLA] = as4(bload4(Rb, voA2[k - C::NLA], (uint32_t)(m0 * lda_b) * 4u));
+    else if (k == NA) r.b[0] = as4(bload4(RB0, voB[0], (uint32_t)(m0 * Bld[0]) * 4u));
+    else if (k == NA + 1) r.b[1] = as4(bload4(RB1, voB[1], (uint32_t)(m0 * Bld[1]) * 4u));
   };
   auto lstore_piece = [&](auto two_tag, const RSet& r, float* S, int k) __attribute__((always_inline)) {
     constexpr bool TWO = decltype(two_tag)::value;
