@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bufres.h"
+
 #include <type_traits>
 
 #include "philox.h"
@@ -143,9 +145,11 @@ __device__ __forceinline__ float tanh_fast(float x) {
 // every operand buffer is allocated with its tiled extent (rows rounded up to the tile, plus a slack
 // tail), rows/cols beyond the matrix feed only output rows/cols the epilogue discards, and weight pad
 // rows are zero.  Branch-free loads are what lets the compiler keep them in flight behind counted waits.
+// The loads are raw buffer loads (bufres.h): resource = the operand from the tile's first row / column on, per-thread byte
+// offsets fixed for the whole launch (tile_offsets), the K position as a SCALAR offset - a global_load's moving 64-bit address is
+// a VALU add per load, and the in-order wave stalls for the add and for the load that waits for it (csrc/dgrad_rows.h).
 template <int LOAD, int ROWS, int BK>
-__device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld, int i0, int k0,
-                                          float4 (&r)[ROWS * BK / 4 / NTHREADS], int tid) {
+__device__ __forceinline__ void tile_offsets(int ld, uint32_t (&vo)[ROWS * BK / 4 / NTHREADS], int tid) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
   constexpr int KQ = BK / 4;   // float4 per row of a k-contiguous operand
 #pragma unroll
@@ -153,12 +157,27 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int ld,
     const int f = tid + s * NTHREADS;
     if (LOAD == LD_KCONTIG) {
       const int i = f / KQ, kq = f % KQ;
-      r[s] = *reinterpret_cast<const float4*>(src + (size_t)(i0 + i) * ld + k0 + 4 * kq);
+      vo[s] = (uint32_t)(i * ld + 4 * kq) * 4u;
     } else {
       constexpr int VPR = ROWS / 4;  // float4 per k-row
       const int k = f / VPR, iq = f - k * VPR;
-      r[s] = *reinterpret_cast<const float4*>(src + (size_t)(k0 + k) * ld + i0 + 4 * iq);
+      vo[s] = (uint32_t)(k * ld + 4 * iq) * 4u;
     }
+  }
+}
+template <int LOAD, int ROWS, int BK>
+__device__ __forceinline__ brsrc tile_resource(const float* __restrict__ src, int ld, int i0) {
+  return make_brsrc(LOAD == LD_KCONTIG ? src + (size_t)i0 * ld : src + i0, 0xffffffffu);
+}
+template <int LOAD, int ROWS, int BK>
+__device__ __forceinline__ void load_tile(brsrc res, const uint32_t (&vo)[ROWS * BK / 4 / NTHREADS], int ld, int k0,
+                                          float4 (&r)[ROWS * BK / 4 / NTHREADS]) {
+  constexpr int NV = ROWS * BK / 4 / NTHREADS;
+  const uint32_t so = (LOAD == LD_KCONTIG ? (uint32_t)k0 : (uint32_t)k0 * (uint32_t)ld) * 4u;
+#pragma unroll
+  for (int s = 0; s < NV; ++s) {
+    const f32x4_b v = bload4(res, vo[s], so);
+    r[s] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -342,10 +361,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   const int aoff = lhi * LDA + wm * (BM / Cfg::WM) + l31;
   const int boff = lhi * LDB + wn * (BN / Cfg::WN) + l31;
 
+  const brsrc resA = tile_resource<LOADA, BM, BK>(p.A, p.lda, m0), resB = tile_resource<LOADB, BN, BK>(p.B, p.ldb, n0);
+  uint32_t voA[NVA], voB[NVB];
+  tile_offsets<LOADA, BM, BK>(p.lda, voA, tid);
+  tile_offsets<LOADB, BN, BK>(p.ldb, voB, tid);
   auto ld = [&](float4 (&xa)[NVA], float4 (&xb)[NVB], int i) {
     const int k0 = kb + min(i, nt - 1) * BK;   // past the end: re-read the last K-step (never consumed)
-    load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid);
-    load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid);
+    load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa);
+    load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb);
   };
   auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
     float* An = smem + stage * Cfg::STAGE;
@@ -473,9 +496,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
           if constexpr (XFA == XF_PRELU) DIAG_ST((store_tile_km<XF_NONE, BM, LDK, BK>(Aw, xa, 0.f, tid)));
           DIAG_ST((store_tile_km<XFB, BN, LDK, BK>(Aw + BOFF, xb, slopeB, tid)));
         } else if (sl == 2 * NQ + 2) {
-          DIAG_LD((load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid)));
+          DIAG_LD((load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa)));
         } else if (sl == 2 * NQ + 3) {
-          DIAG_LD((load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid)));
+          DIAG_LD((load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb)));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -572,8 +595,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         }
         if (g == G / 2) store_tile<LOADA, XFA, BM, LDA, BK>(Aw, xa, slopeA, tid);
         else if (g == G / 2 + 1) store_tile<LOADB, XFB, BN, LDB, BK>(Aw + BOFF, xb, slopeB, tid);
-        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(p.A, p.lda, m0, k0, xa, tid);
-        else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(p.B, p.ldb, n0, k0, xb, tid);
+        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa);
+        else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
