@@ -46,8 +46,10 @@ int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
 int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on);
 /* Row-owned input gradients (csrc/dgrad_rows.h: one work-group per CU owns 96 stacked rows and every column of a layer's input
  * gradient, operands straight from global memory, PReLU' and the slope partial sums on 16-byte quads) behind the row-owned
- * forward: 1 (default) on, 0 the 64x64-tile launches; also env SDRM_DGRAD_ROWS.  Takes effect with the next backward. */
-int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int on);
+ * forward: 1 (default) the loss value, the gradient seeds and every layer's dgrad in ONE launch (k_dgrad_chain: rows never meet, a
+ * work-group runs down the chain on its own), 2 k_loss_seed + one k_dgrad_rows launch per layer, 0 k_loss_seed + the 64x64-tile
+ * launches; also env SDRM_DGRAD_ROWS.  Takes effect with the next backward. */
+int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int mode);
 /* 1 when this engine's shape qualifies for the row-owned forward (its fragment-packed weight copies exist). */
 int sdrm_debug_rowchain_available(const sdrm_engine* e);
 /* Fusion of the DDPM reverse update into the out-layer GEMM epilogue (full-resolution sampling with on-device Philox;

@@ -118,16 +118,16 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
   }
 }
 
+// one layer for the work-group's 96 rows (block index g); `red`: four floats of LDS
 template <int CT>
-__global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs a) {
+__device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red) {
   constexpr int NP = 32 * CT, NCT = 2 * CT, KS = NP / 16, NQ = 3 * CT;
   static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
-  __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int li = lane & 15, lq = lane >> 4;
-  const size_t grow0 = (size_t)RC_ROWS * blockIdx.x;
+  const size_t grow0 = (size_t)RC_ROWS * g;
   const uint32_t lane16 = 16u * (uint32_t)lane;
 #ifdef DR_STAMPS
   unsigned long long st_[8] = {0};
@@ -207,14 +207,123 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs 
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if (lane == 0) red[wave] = part;
   __syncthreads();
-  if (tid == 0) a.slope_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid == 0) a.slope_part[g] = (red[0] + red[1]) + (red[2] + red[3]);
 #ifdef DR_STAMPS
   DR_STAMP(4);
   if (tid == 0 && a.stamps) {
     st_[5] = __builtin_amdgcn_s_memrealtime();
-    for (int i = 0; i < 8; ++i) a.stamps[8 * (size_t)blockIdx.x + i] = st_[i];
+    for (int i = 0; i < 8; ++i) a.stamps[8 * (size_t)g + i] = st_[i];
   }
 #endif
+}
+
+
+template <int CT>
+__global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs a) {
+  __shared__ float red[4];
+  dr_layer<CT>(a, (int)blockIdx.x, red);
+}
+
+// The whole input-gradient chain of a train step in ONE launch: the loss value and the closed-form gradient seeds of the
+// work-group's 32 users (k_loss_seed's arithmetic, elementwise.h, with 1 / mu^2 as a multiply), then every layer's dgrad from the output layer
+// down - rows never meet, so a work-group runs down the chain on its own: between two layers only its own stores have to land
+// (a barrier).  Two launches and the seeds' own pass over Y fewer than k_loss_seed + one k_dgrad_rows per layer.
+constexpr int DR_MAX_LAYERS = 8;
+struct DgradChainArgs {
+  SeedArgs seed;                      // dY = the chain's first input; grouped row order
+  int nlayers;                        // H + 1
+  DgradRowsArgs layer[DR_MAX_LAYERS];
+  unsigned long long* seed_stamps;    // diagnostic builds only (-DDR_STAMPS): cycles of the seed stage per work-group
+};
+
+template <int CT>
+__global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_chain(const DgradChainArgs c) {
+  __shared__ float red[4];
+  __shared__ double shs[4], tot[4];
+  const SeedArgs& a = c.seed;
+  const int tid = threadIdx.x, g = blockIdx.x;
+#ifdef DR_STAMPS
+  const unsigned long long t_seed0 = __builtin_amdgcn_s_memtime();
+#endif
+  {
+    // the five sums: given (sharded step, after the all-reduce) or folded here from the forward's per-work-group partials,
+    // exactly as k_loss_seed does
+    double s0, s1, s2, s3, N;
+    if (a.sums) {
+      s0 = a.sums[0]; s1 = a.sums[1]; s2 = a.sums[2]; s3 = a.sums[3]; N = a.sums[4];
+    } else {
+      double v[4] = {0, 0, 0, 0};
+      for (int i = tid; i < a.nblk; i += NTHREADS)
+        for (int j = 0; j < 4; ++j) v[j] += a.part[4 * (size_t)i + j];
+      for (int j = 0; j < 4; ++j) {
+        const double t = block_sum(v[j], shs);
+        if (tid == 0) tot[j] = t;
+      }
+      __syncthreads();
+      s0 = tot[0]; s1 = tot[1]; s2 = tot[2]; s3 = tot[3]; N = a.count;
+    }
+    const double A = s0 / N, C = s1 / N, Rbar = s2 / N;
+    const double V = (N > 1.0) ? (s3 - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
+    const double den = 1e-8 + V;
+    const double k = 0.5 / den;
+    const float cD = (float)(2.0 * k / N);
+    const float cV = (float)(-(0.5 * (A + C) / (den * den)) * 2.0 / (N - 1.0));
+    const float rbar = (float)Rbar;
+    if (g == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + C) / den);
+    // thread -> (user tid / 8 of the group, column quads tid % 8 + 8 j)
+    const int su = tid >> 3, sq = tid & 7, r = RC_USERS * g + su;
+    const size_t rowP = (size_t)RC_ROWS * g + su;
+    // every quad of the thread is requested before the first is used: one HBM round trip, not CT of them
+    float4 P4[CT], S4[CT], Q4[CT], X4[CT];
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int col = 4 * (sq + 8 * j);
+      const size_t yP = rowP * a.LP + col, yS = yP + (size_t)RC_USERS * a.LP, yQ = yS + (size_t)RC_USERS * a.LP;
+      const bool ok = r < a.B && col < a.L;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      P4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yP) : z;
+      S4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yS) : z;
+      Q4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yQ) : z;
+      X4[j] = ok ? load4_unpadded(a.x0, r, col, a.L) : z;
+    }
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      const int col = 4 * (sq + 8 * j);
+      const size_t yP = rowP * a.LP + col, yS = yP + (size_t)RC_USERS * a.LP, yQ = yS + (size_t)RC_USERS * a.LP;
+      float gP[4] = {0.f, 0.f, 0.f, 0.f}, gS[4] = {0.f, 0.f, 0.f, 0.f}, gQ[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < a.B && col < a.L) {
+        const float p_[4] = {P4[j].x, P4[j].y, P4[j].z, P4[j].w}, s_[4] = {S4[j].x, S4[j].y, S4[j].z, S4[j].w},
+                    q_[4] = {Q4[j].x, Q4[j].y, Q4[j].z, Q4[j].w}, x_[4] = {X4[j].x, X4[j].y, X4[j].z, X4[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (col + i < a.L) {
+            const float P = p_[i], S = s_[i], Q = q_[i];
+            const float R = P - x_[i];
+            // 1 / mu^2 as a multiply (as the forward's loss sums do): an IEEE division is ten instructions, three of them per
+            // element made this stage 41 k cycles of the launch - one wave per SIMD has no second wave to hide them behind
+            const float D = (Q - S) * (1.f / MU2) - R;
+            const float gD = cD * D;
+            const float gC = cD * (R - S);
+            const float gV = cV * (R - rbar);
+            const float gDm = gD * (1.f / MU2);
+            gP[i] = (-gD + gC + gV) * (1.f - P * P);
+            gQ[i] = gDm * (1.f - Q * Q);
+            gS[i] = (-gDm - gC) * (1.f - S * S);
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(a.dY + yP) = make_float4(gP[0], gP[1], gP[2], gP[3]);
+      *reinterpret_cast<float4*>(a.dY + yS) = make_float4(gS[0], gS[1], gS[2], gS[3]);
+      *reinterpret_cast<float4*>(a.dY + yQ) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
+    }
+  }
+#ifdef DR_STAMPS
+  if (tid == 0 && c.seed_stamps) c.seed_stamps[g] = __builtin_amdgcn_s_memtime() - t_seed0;
+#endif
+  for (int l = 0; l < c.nlayers; ++l) {
+    __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
+    dr_layer<CT>(c.layer[l], g, red);
+  }
 }
 
 }  // namespace sdrm

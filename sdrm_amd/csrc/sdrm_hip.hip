@@ -56,7 +56,8 @@ struct Tuning {
   int wgrad_round = 1280;        // SDRM_WGRAD_ROUND: ... unless ONE round (this many work-groups) already gives eight slices or more
   int wgrad_slices = 0;          // SDRM_WGRAD_SLICES: > 0 forces the K-slice count of every weight-gradient problem (tuning aid)
   int ar_buckets = 1;            // SDRM_AR_BUCKETS: gradient all-reduces of sdrm_train_step_sharded: 1 (after the whole backward) or 2 (overlapped)
-  int dgrad_rows = 1;            // SDRM_DGRAD_ROWS: row-owned input gradients (csrc/dgrad_rows.h) behind the row-owned forward: 0 off
+  int dgrad_rows = 1;            // SDRM_DGRAD_ROWS: row-owned input gradients (csrc/dgrad_rows.h) behind the row-owned forward: 0 off,
+                                 // 1 the whole chain (loss seeds + every layer) in one launch, 2 k_loss_seed + one launch per layer
   int strips = 1;                // SDRM_WGRAD_STRIPS: strip-owned weight gradients (csrc/wgrad2.h) behind the row-owned forward: 0 off
   int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
                                  // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
@@ -163,7 +164,7 @@ static const char* kProfNames[PC_COUNT] = {
     "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)",
     "train: k_row_fwd row-owned forward (staging + all layers + loss partial sums, one work-group per CU)",
     "train: k_wgrad_strips weight gradients of all layers (strip-owned split-K, one work-group per CU)",
-    "train: k_dgrad_rows input gradient of one layer (row-owned, prelu' epilogue, one work-group per CU)"};
+    "train: k_dgrad_chain / k_dgrad_rows input gradients (row-owned, prelu' epilogue, one work-group per CU; the chain: loss seeds + every layer in one launch)"};
 
 namespace {
 
@@ -586,10 +587,16 @@ int launch_dgrad_rows_ct(sdrm_engine* e, const DgradRowsArgs& a, int G, double f
 }
 
 // out[MP][WP] = (G[MP][WP] * W) * prelu'(pre), W given as the fragment-packed [k = out][n = in] copy
-int launch_dgrad_rows(sdrm_engine* e, const float* G, const float* WfT, const float* pre, const float* slope, float* out, float* partial,
-                      int MP, double flops, hipStream_t st) {
+DgradRowsArgs dgrad_rows_args(const sdrm_engine* e, const float* G, const float* WfT, const float* pre, const float* slope, float* out,
+                              float* partial) {
   DgradRowsArgs a{};
   a.G = G; a.ldg = e->WP; a.WfT = WfT; a.pre = pre; a.ldp = e->WP; a.slope = slope; a.out = out; a.ldo = e->WP; a.slope_part = partial;
+  return a;
+}
+
+int launch_dgrad_rows(sdrm_engine* e, const float* G, const float* WfT, const float* pre, const float* slope, float* out, float* partial,
+                      int MP, double flops, hipStream_t st) {
+  const DgradRowsArgs a = dgrad_rows_args(e, G, WfT, pre, slope, out, partial);
   const int Gn = MP / RC_ROWS;
   switch (e->WP / 32) {
     case 4: return launch_dgrad_rows_ct<4>(e, a, Gn, flops, st);
@@ -600,6 +607,37 @@ int launch_dgrad_rows(sdrm_engine* e, const float* G, const float* WfT, const fl
     case 9: return launch_dgrad_rows_ct<9>(e, a, Gn, flops, st);
     case 10: return launch_dgrad_rows_ct<10>(e, a, Gn, flops, st);
     default: return launch_dgrad_rows_ct<11>(e, a, Gn, flops, st);
+  }
+}
+
+// loss value + gradient seeds + every layer's dgrad in one launch (k_dgrad_chain)
+template <int CT>
+int launch_dgrad_chain_ct(sdrm_engine* e, const DgradChainArgs& a, int G, double flops, hipStream_t st) {
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_DGRAD_ROWS);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_DGRAD_ROWS);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  SDRM_LAUNCH(e, (k_dgrad_chain<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  return SDRM_OK;
+}
+
+int launch_dgrad_chain(sdrm_engine* e, const DgradChainArgs& a, int MP, double flops, hipStream_t st) {
+  const int Gn = MP / RC_ROWS;
+  switch (e->WP / 32) {
+    case 4: return launch_dgrad_chain_ct<4>(e, a, Gn, flops, st);
+    case 5: return launch_dgrad_chain_ct<5>(e, a, Gn, flops, st);
+    case 6: return launch_dgrad_chain_ct<6>(e, a, Gn, flops, st);
+    case 7: return launch_dgrad_chain_ct<7>(e, a, Gn, flops, st);
+    case 8: return launch_dgrad_chain_ct<8>(e, a, Gn, flops, st);
+    case 9: return launch_dgrad_chain_ct<9>(e, a, Gn, flops, st);
+    case 10: return launch_dgrad_chain_ct<10>(e, a, Gn, flops, st);
+    default: return launch_dgrad_chain_ct<11>(e, a, Gn, flops, st);
   }
 }
 
@@ -831,7 +869,7 @@ int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
 
 int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
-  e->tune.dgrad_rows = on ? 1 : 0;
+  e->tune.dgrad_rows = on < 0 ? 0 : (on > 2 ? 2 : on);
   return SDRM_OK;
 }
 
@@ -1211,7 +1249,9 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_grouped ? 1 : 0;
   sa.part = e->loss_part; sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
-  {
+  // the row-owned chain (dgrad_rows.h) computes the seeds itself; every other path launches k_loss_seed
+  const bool chain = use_dgrad_rows(e, MP) && e->tune.dgrad_rows == 1 && H + 1 <= DR_MAX_LAYERS;
+  if (!chain) {
     const int nslots = e->cur_grouped ? RC_USERS * ((B + RC_USERS - 1) / RC_USERS) : B;
     const unsigned need = (unsigned)(((size_t)(nslots + (MP - 3 * nslots)) * (e->LP / 4) + 255) / 256);
     dim3 grid(std::min(need, 2048u));   // grid-stride beyond: see k_loss_seed
@@ -1243,12 +1283,23 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     return SDRM_OK;
   }
   if (use_dgrad_rows(e, MP)) {
-    // one work-group per 96 stacked rows and layer: one slope partial per work-group
-    int rc = launch_dgrad_rows(e, e->dY, e->WofT, pre_buf(e, H), slope_ptr(e, H), dpre_buf(e, H),
-                               e->alpha_part + (size_t)H * e->alpha_part_stride, MP, flO, st);
-    for (int k = H; k >= 1 && !rc; --k)
-      rc = launch_dgrad_rows(e, dpre_buf(e, k), e->WhfT, pre_buf(e, k - 1), slope_ptr(e, k - 1), dpre_buf(e, k - 1),
-                             e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, MP, flH, st);
+    // one work-group per 96 stacked rows (and layer): one slope partial per work-group
+    int rc = SDRM_OK;
+    if (chain) {
+      DgradChainArgs ca{};
+      ca.seed = sa; ca.nlayers = H + 1;
+      ca.layer[0] = dgrad_rows_args(e, e->dY, e->WofT, pre_buf(e, H), slope_ptr(e, H), dpre_buf(e, H), e->alpha_part + (size_t)H * e->alpha_part_stride);
+      for (int k = H; k >= 1; --k)
+        ca.layer[H + 1 - k] = dgrad_rows_args(e, dpre_buf(e, k), e->WhfT, pre_buf(e, k - 1), slope_ptr(e, k - 1), dpre_buf(e, k - 1),
+                                              e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride);
+      rc = launch_dgrad_chain(e, ca, MP, flO + H * flH, st);
+    } else {
+      rc = launch_dgrad_rows(e, e->dY, e->WofT, pre_buf(e, H), slope_ptr(e, H), dpre_buf(e, H),
+                             e->alpha_part + (size_t)H * e->alpha_part_stride, MP, flO, st);
+      for (int k = H; k >= 1 && !rc; --k)
+        rc = launch_dgrad_rows(e, dpre_buf(e, k), e->WhfT, pre_buf(e, k - 1), slope_ptr(e, k - 1), dpre_buf(e, k - 1),
+                               e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride, MP, flH, st);
+    }
     if (rc) return rc;
     if (with_wgrad0)
       HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,

@@ -85,7 +85,7 @@ class Engine:
         if wgrad_strips is not None:
             self._check(self.lib.sdrm_debug_set_wgrad_strips(self._h, int(bool(wgrad_strips))), "sdrm_debug_set_wgrad_strips")
         if dgrad_rows is not None:
-            self._check(self.lib.sdrm_debug_set_dgrad_rows(self._h, int(bool(dgrad_rows))), "sdrm_debug_set_dgrad_rows")
+            self._check(self.lib.sdrm_debug_set_dgrad_rows(self._h, int(dgrad_rows)), "sdrm_debug_set_dgrad_rows")
         if gradient_buckets is not None:
             self._check(self.lib.sdrm_debug_set_gradient_buckets(self._h, int(gradient_buckets)), "sdrm_debug_set_gradient_buckets")
             self.gradient_buckets = int(gradient_buckets)

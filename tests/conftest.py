@@ -40,13 +40,15 @@ def engine_cls():
 
     class TestEngine(Engine):
         def debug_set(self, **kw):
-            if kw.get("tile") in ("row", "row-tiles"):
+            if kw.get("tile") in ("row", "row-layers", "row-tiles"):
                 if not self.rowchain_available:
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope")
-                # "row": the row-owned forward with the row-owned dgrads and the strip-owned weight gradients behind it (the
-                # default pairing); "row-tiles": the same forward with the 64x64-tile dgrad and batched split-K launches
-                kw = dict(kw, tile=None, rowchain=2, wgrad_strips=kw["tile"] == "row", dgrad_rows=kw["tile"] == "row")
+                # "row": the row-owned forward with the row-owned dgrad chain (one launch) and the strip-owned weight gradients
+                # behind it (the default pairing); "row-layers": the same with k_loss_seed + one row-owned dgrad launch per layer;
+                # "row-tiles": the same forward with the 64x64-tile dgrad and batched split-K launches
+                mode = kw["tile"]
+                kw = dict(kw, tile=None, rowchain=2, wgrad_strips=mode != "row-tiles", dgrad_rows={"row": 1, "row-layers": 2, "row-tiles": 0}[mode])
             return super().debug_set(**kw)
 
     return TestEngine

@@ -41,7 +41,7 @@ def sampler_path(request):
 
 TILES = [-1, 0, 4]   # automatic; forced 64x64x16 (32-wide MFMA); forced 32x32x32 (16-wide MFMA): every step-level test
                      # below runs on each, so a size-threshold retune cannot change which kernels the suite covers
-TRAIN_PATHS = TILES + ["row", "row-tiles"]   # train-step tests also run through the row-owned forward (csrc/rowchain.h, grouped row order)
+TRAIN_PATHS = TILES + ["row", "row-layers", "row-tiles"]   # train-step tests also run through the row-owned forward (csrc/rowchain.h, grouped row order)
 
 
 @pytest.fixture(params=TILES, ids=lambda t: f"tile{t}")
@@ -142,7 +142,7 @@ def test_train_golden(engine_cls, golden, train_path, fixture):
     gradient tensor (shared hidden layer accumulation, Q1), post-Adam parameters across the
     epoch boundary, final Adam moments.  `train_wide` holds a net inside the row-owned forward's envelope."""
     tile = train_path
-    if tile in ("row", "row-tiles") and fixture != "train_wide":
+    if tile in ("row", "row-layers", "row-tiles") and fixture != "train_wide":
         pytest.skip("no case of this fixture lies inside the row-owned forward's envelope")
     g = golden(fixture)
     for ci in range(int(g["n_cases"])):
@@ -321,7 +321,7 @@ def test_narrow_net_train_paths_agree(engine_cls, dims):
         assert rel_l2(w1, w0) <= TOL, mode   # Adam's first step is lr*sign(g): a sign flip of a ~0 gradient moves a weight by 2*lr
 
 
-@pytest.mark.parametrize("path", [-1, "row", "row-tiles"])
+@pytest.mark.parametrize("path", [-1, "row", "row-layers", "row-tiles"])
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (41, 40, 93, 5, 50), (24, 24, 9, 2, 7), (130, 130, 12, 2, 77)])
 def test_philox_mode_train(engine_cls, dims, path):
     """PHILOX mode == EXPLICIT mode fed with the numpy restatement of the device generator: integer
@@ -409,7 +409,7 @@ def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
         return loss, g, p
 
     ref = grads(-1)
-    for path, two_call in (("row", False), ("row-tiles", False), ("row", True)):
+    for path, two_call in (("row", False), ("row-layers", False), ("row-tiles", False), ("row", True)):
         loss, g, p = grads(path, two_call)
         assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0])
         for (n, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(ref[1], (L, W, T, H))):

@@ -138,8 +138,60 @@ int main(int argc, char** argv) {
            (double)(rt[grid - 1] - rt[0]) / 100.0);
   }
 #endif
+  // the chain: loss seeds + two layers (output layer, hidden layer) in one launch, on synthetic Y / x0 / partial sums
+  DgradChainArgs ch{};
+  {
+    const int B = RC_USERS * grid;
+    std::vector<float> hY((size_t)MP * NP), hX((size_t)B * W);
+    std::uniform_real_distribution<float> uni(-0.9f, 0.9f);
+    for (auto& v : hY) v = uni(rng);
+    for (auto& v : hX) v = uni(rng);
+    std::vector<double> hpartd(4 * (size_t)grid);
+    for (int gi = 0; gi < grid; ++gi) { hpartd[4 * gi] = 30.0; hpartd[4 * gi + 1] = 20.0; hpartd[4 * gi + 2] = 1.0; hpartd[4 * gi + 3] = 900.0; }
+    float *dY2 = dalloc<float>(hY.size()), *dX = dalloc<float>(hX.size()), *dG1 = dalloc<float>(hG.size()), *dloss = dalloc<float>(1);
+    double* dpd = dalloc<double>(hpartd.size());
+    CHECK(hipMemcpy(dY2, hY.data(), hY.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dX, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dpd, hpartd.data(), hpartd.size() * 8, hipMemcpyHostToDevice));
+    ch.seed.sums = nullptr; ch.seed.Y = dY2; ch.seed.x0 = dX; ch.seed.dY = dG; ch.seed.loss = dloss;
+    ch.seed.B = B; ch.seed.L = W; ch.seed.LP = NP; ch.seed.MP = MP; ch.seed.grouped = 1;
+    ch.seed.part = dpd; ch.seed.nblk = grid; ch.seed.count = (double)B * W;
+    ch.nlayers = 2;
+    ch.layer[0] = a; ch.layer[0].out = dG1;
+    ch.layer[1] = a; ch.layer[1].G = dG1; ch.layer[1].out = dO; ch.layer[1].slope_part = dpart + 4096;
+  }
+  auto launch_chain = [&]() { hipLaunchKernelGGL((k_dgrad_chain<CT>), dim3(grid), dim3(NTHREADS), 0, 0, ch); };
+#ifdef DR_STAMPS
+  {
+    unsigned long long* dss = dalloc<unsigned long long>(grid);
+    ch.seed_stamps = dss;
+    for (int k = 0; k < 10; ++k) launch_chain();
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(grid);
+    CHECK(hipMemcpy(h.data(), dss, grid * 8, hipMemcpyDeviceToHost));
+    ch.seed_stamps = nullptr;
+    std::sort(h.begin(), h.end());
+    printf("# chain: seed stage %llu / %llu / %llu cycles (median / p90 / max over %d work-groups)\n", h[grid / 2], h[grid * 9 / 10], h[grid - 1], grid);
+  }
+#endif
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  {
+    launch_chain();
+    std::vector<float> t;
+    for (int r = 0; r < 7; ++r) {
+      CHECK(hipEventRecord(e0, 0));
+      for (int k = 0; k < 20; ++k) launch_chain();
+      CHECK(hipEventRecord(e1, 0));
+      CHECK(hipEventSynchronize(e1));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      t.push_back(ms * 1e3f / 20);
+    }
+    std::sort(t.begin(), t.end());
+    printf("%-40s med %7.2f us  min %7.2f us\n", "chain: seeds + 2 layers, one launch", t[3], t[0]);
+    CHECK(hipMemcpy(dG, hG.data(), hG.size() * 4, hipMemcpyHostToDevice));   // the seeds overwrote the probe's G
+  }
   std::vector<float> us[2];
   for (int r = 0; r < 7; ++r)
     for (int v = 0; v < 2; ++v) {
