@@ -89,7 +89,7 @@ struct RowChainCfg {
 // one K-step of a wave: 12 * CT MFMAs out of (ac, bc); in their shadows the next step's B fragments (global) and A fragments
 // (LDS) land in (an, bn), and two chunks of the activation tile are streamed LDS -> HBM
 // diagnostic builds only (-DRC_DIAG=mask): drop a piece of the main loop to see what it costs - bit0 the tile stream, bit1 the B
-// fragment loads, bit2 the A fragment reads
+// fragment loads, bit2 the A fragment reads, bit3 the pre-activation stores of the epilogues
 #ifndef RC_DIAG
 #define RC_DIAG 0
 #endif
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const f32x4 v = acc[rt][ct];
-          gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+          if (!(RC_DIAG & 8)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
           *reinterpret_cast<float4*>(otile + rt * RC_USERS * LDA + 16 * ct) =
               make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
         }

@@ -1,0 +1,147 @@
+"""ISA lint of the row-owned kernels (csrc/rowchain.h, csrc/dgrad_rows.h): their MFMAs are inline asm with the accumulator tied
+in place (the register allocator otherwise renames accumulators inside the K loops and copies them back by the hundred), so the
+compiler's hazard recogniser does not see them.  The sources guard the two places where compiler-made VALU code meets the
+accumulators (rc_acc_begin / rc_acc_settle); this test cross-compiles the kernels for gfx950 (no GPU needed) and checks the
+generated code for any other:
+
+  * no accumulator copy or write (v_accvgpr_*) inside a K loop, no scratch access inside a K loop;
+  * an accumulator write by VALU (v_accvgpr_write / v_accvgpr_mov) is never closer than two wait states to the next MFMA;
+  * the first accumulator read (v_accvgpr_read) after an MFMA is separated from it by at least 18 wait states of s_nop
+    (v_mfma_f32_16x16x4_f32: 8 passes; the CDNA3 ISA guide asks for 11 before a VALU read of the result);
+  * no VALU instruction inside the K loops of the dgrad kernels at all (operands by raw buffer loads with scalar offsets).
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "sdrm_amd", "csrc")
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    pytest.skip("hipcc not available")
+
+
+def _compile(instantiations: str) -> str:
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "k.hip")
+        with open(src, "w") as f:
+            f.write(f'#include "{CSRC}/dgrad_rows.h"\n' + instantiations)
+        out = os.path.join(d, "k.s")
+        res = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        return open(out).read()
+
+
+def _kernels(asm: str):
+    """name -> list of instruction strings (labels kept as 'LABEL name')."""
+    out, cur = {}, None
+    for line in asm.split("\n"):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        if cur is None:
+            continue
+        t = line.strip()
+        if re.match(r"^\.LBB\d+_\d+:", t):
+            cur.append("LABEL " + t.split(":")[0])
+        elif line.startswith("\t") and t and not t.startswith(";") and not t.startswith("."):
+            cur.append(t.split(";")[0].strip())
+            if t.startswith("s_endpgm"):
+                cur = None
+    return out
+
+
+def _loops(ins):
+    """(start, end) index ranges of the basic-block loops: a label and the first backward branch to it."""
+    labels = {x.split()[1]: i for i, x in enumerate(ins) if x.startswith("LABEL ")}
+    loops = []
+    for i, x in enumerate(ins):
+        m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", x)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    return loops
+
+
+def _wait_states(x):
+    m = re.match(r"s_nop (\d+)", x)
+    return int(m.group(1)) + 1 if m else (0 if x.startswith("LABEL") else 1)
+
+
+VALU_OK_IN_LOOP = ("v_mfma",)
+
+
+@pytest.mark.parametrize("ct", [4, 11])
+def test_row_owned_kernels_isa(ct):
+    asm = _compile(f"template __global__ void sdrm::k_dgrad_chain<{ct}>(const sdrm::DgradChainArgs);\n"
+                   f"template __global__ void sdrm::k_dgrad_rows<{ct}>(const sdrm::DgradRowsArgs);\n"
+                   f"template __global__ void sdrm::k_row_fwd<{ct}>(const sdrm::RowChainArgs);\n")
+    ks = _kernels(asm)
+    names = {"chain": [n for n in ks if "k_dgrad_chain" in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
+             "fwd": [n for n in ks if "k_row_fwd" in n]}
+    assert all(len(v) == 1 for v in names.values()), names
+    for kind, (name,) in names.items():
+        ins = ks[name]
+        mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
+        assert len(mf) >= 100, (kind, len(mf))
+        # K loops: the loops that hold MFMAs
+        loops = _loops(ins)
+        inner = [(a, b) for a, b in loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in loops)]
+        # (the layer loops have barriers, a K loop has none)
+        kloops = [(a, b) for a, b in inner if sum(1 for x in ins[a:b] if x.startswith("v_mfma")) >= 24 and "s_barrier" not in ins[a:b]]
+        # (a K loop of a single trip is straight-line code: the narrowest nets of the dgrad kernels)
+        assert kloops or (kind != "fwd" and ct <= 5), kind
+        for a, b in kloops:
+            body = ins[a:b]
+            assert not [x for x in body if x.startswith("v_accvgpr")], (kind, "accumulator copies inside a K loop")
+            assert not [x for x in body if x.startswith("scratch_")], (kind, "scratch access inside a K loop")
+            if kind != "fwd":
+                valu = [x for x in body if x.startswith("v_") and not x.startswith(VALU_OK_IN_LOOP)]
+                assert not valu, (kind, "VALU inside a K loop", valu[:4])
+            else:
+                # the forward keeps a handful per pair of K-steps: LDS addresses of the A fragment reads and of the stream chunks
+                valu = [x for x in body if x.startswith("v_") and not x.startswith(VALU_OK_IN_LOOP)]
+                assert len(valu) <= 16, (kind, len(valu), valu[:6])
+        # hazards around the asm MFMAs
+        for i in mf:
+            ws = 0
+            for j in range(i - 1, max(i - 4, -1), -1):
+                x = ins[j]
+                if x.startswith(("v_accvgpr_write", "v_accvgpr_mov")):
+                    assert ws >= 2, (kind, "VALU write of an accumulator %d wait states before an MFMA" % ws, ins[j:i + 1])
+                ws += _wait_states(x)
+                if ws >= 2:
+                    break
+        # accumulator reads: along every path out of an MFMA (branches followed), 18 wait states of s_nop come first
+        labels = {x.split()[1]: i for i, x in enumerate(ins) if x.startswith("LABEL ")}
+
+        def walk(i, nops, budget, seen):
+            while i < len(ins) and budget > 0 and nops < 18:
+                x = ins[i]
+                if x.startswith("v_mfma") or x.startswith("s_endpgm"):
+                    return
+                assert not x.startswith("v_accvgpr_read"), (kind, "accumulator read %d nop states after an MFMA" % nops, ins[max(0, i - 6):i + 1])
+                m = re.match(r"s_(c?branch)\w* (\.LBB\d+_\d+)", x)
+                if m:
+                    tgt = labels[m.group(2)]
+                    if (tgt, nops) not in seen:
+                        seen.add((tgt, nops))
+                        walk(tgt, nops, budget - 1, seen)
+                    if m.group(1) == "branch":
+                        return
+                nops += _wait_states(x) if x.startswith("s_nop") else 0
+                i += 1
+                budget -= 1
+
+        for i in mf:
+            if not ins[i + 1].startswith("v_mfma"):
+                walk(i + 1, 0, 96, set())
