@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
   a.W0f = dWf[0]; a.Whf = dWf[1]; a.Wof = dWf[2]; a.bh = dbh; a.bo = dbo; a.B0tab = dB0tab; a.ldtab = NP;
   a.slope0 = dsl; a.slopeh = dsl + 1;
   a.U = dU; a.K0 = K0; a.LPs = NP; a.tdev = dtdev; a.pre = dpre; a.pre_stride = (size_t)MP * NP; a.ldp = NP; a.Y = dY; a.ldy = NP;
-  a.loss_part = dpart; a.act = dact;
+  a.loss_part = dpart; a.act = dact; a.ones_col = -1;
 
   auto launch_row = [&](int mode) {
     RowChainArgs b = a;
