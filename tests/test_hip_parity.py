@@ -382,7 +382,11 @@ def test_weight_gradients_at_any_slice_count(engine_cls, monkeypatch, dims, slic
     assert l2 == l1 and np.array_equal(g2, g1)      # the two-call backward adds the same slices in the same order
 
 
-@pytest.mark.parametrize("dims", [(136, 136, 12, 2, 75), (340, 340, 78, 1, 300), (100, 100, 7, 0, 40)])
+@pytest.mark.parametrize("dims", [(136, 136, 12, 2, 75), (340, 340, 78, 1, 300), (100, 100, 7, 0, 40),
+                                  # every padded width of the row-owned kernels' envelope (6 .. 10 column tiles of 32: each has its own
+                                  # instantiation, and its own split of the K loop into trips and peeled K-steps)
+                                  (180, 180, 9, 1, 40), (200, 200, 9, 1, 40), (250, 250, 20, 1, 70), (280, 280, 6, 2, 33),
+                                  (310, 310, 6, 1, 33)])
 def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
     """Behind the row-owned forward (grouped row order, stored activations, ones column) the three backward forms must agree:
     one call with the strip-owned weight gradients (bias gradients from the ones column of the slabs), one call with the
@@ -414,7 +418,12 @@ def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
         assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0])
         for (n, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(ref[1], (L, W, T, H))):
             assert rel_l2(a, b) <= 2e-5 and rel_max(a, b) <= 1e-4, (path, two_call, n, rel_l2(a, b), rel_max(a, b))
-        assert rel_l2(p, ref[2]) <= 1e-5
+        # Adam's first update is lr * sign(g + wd p) wherever |g| >> eps: an element whose gradient cancels to ~1e-7 can land on
+        # either side of zero with the summation order (a handful per net); those are checked for exactly that, the rest to 1e-5
+        off = np.abs(p - ref[2]) > 1e-4
+        assert int(off.sum()) <= 4, (path, two_call, int(off.sum()))
+        assert np.all(np.abs(g[off] + 1e-4 * init[off]) <= 2e-6) and np.all(np.abs(ref[1][off] + 1e-4 * init[off]) <= 2e-6)
+        assert rel_l2(p[~off], ref[2][~off]) <= 1e-5
 
 
 @pytest.mark.parametrize("fused", [0, 1, 2])
