@@ -20,6 +20,9 @@ typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4_b bload4(brsrc r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(f32x4_b, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
+__device__ __forceinline__ float bload1(brsrc r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
 // NT: the non-temporal hint - bytes nobody reads before the weight gradients, a whole backward chain later (U, the activations):
 // they should not push the pre-activations and Y, which the loss seeds and the dgrads read next, out of the caches
 template <bool NT>

@@ -50,11 +50,14 @@ struct DgradRowsArgs {
 // next K-step (NB = CT of them -> B[(PH + 1) & 1]), the G fragments of the K-step after that (NA = 3 -> A[(PH + 2) & 3]), and NPRE
 // pre-activation quads (-> pq[PRE0 ..], flat index rt * CT + ct).  One basic block, every load pinned at its slot through an
 // opaque scalar base (see rc_kstep).
-template <int CT, int PH, int NA, int NB, int PRE0, int NPRE>
+// MODE (rowchain.h): RC_NEXT_LIGHT - the G pieces fetch the compact fragments of the layer's last K-step (one float per lane at
+// k = 16 ks + lane group: `goff` then holds those offsets); RC_LIGHT - this is that K-step: one MFMA per tile.
+template <int CT, int PH, int NA, int NB, int PRE0, int NPRE, int MODE = RC_PLAIN>
 __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc gr, uint32_t gnext,
                                          const uint32_t (&goff)[3], brsrc wr_, uint32_t wnext, uint32_t lane16, f32x4 (&pq)[3 * CT],
                                          brsrc pr, const uint32_t (&poff)[3]) {
-  constexpr int NSLOT = 12 * CT, NPIECE = NB + NA + NPRE;
+  constexpr int NE = MODE == RC_LIGHT ? 1 : 4;
+  constexpr int NSLOT = 3 * NE * CT, NPIECE = NB + NA + NPRE;
   // the pieces go to the FRONT of the K-step, one per DR_PIECE_STRIDE MFMAs (behind an MFMA a load's issue is free)
   constexpr int STRIDE = NPIECE > 0 ? (NSLOT / NPIECE >= DR_PIECE_STRIDE ? DR_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1)) : NSLOT;
   static_assert(NPIECE <= NSLOT, "not enough MFMA slots for the pipeline pieces");
@@ -63,7 +66,7 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
   f32x4 (&al)[3] = A[(PH + 2) & 3];
   f32x4 (&bl)[CT] = B[(PH + 1) & 1];
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < NE; ++e)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -88,7 +91,8 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
         if (!(DR_DIAG & 2)) {
           uint32_t so = gnext;
           asm volatile("" : "+s"(so));
-          al[p - NB] = bload4(gr, goff[p - NB], so);
+          if (MODE == RC_NEXT_LIGHT) al[p - NB][0] = bload1(gr, goff[p - NB], so);
+          else al[p - NB] = bload4(gr, goff[p - NB], so);
         }
       } else {
         const int q = PRE0 + (p - NB - NA), rt2 = q / CT, ct2 = q % CT;
@@ -104,22 +108,26 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
 // the last PEEL K-steps, straight-line: K-step KS - PEEL + J has phase J & 3 (KS - PEEL is a multiple of four), fetches what is
 // still to come, and takes its share of the 3 * CT pre-activation quads - spread over all of them: in the last two K-steps alone
 // they are a 35 MB burst chip-wide, more than HBM delivers in that time
-template <int CT, int KS, int PEEL, int J>
+// LIGHT: K-step KS - 1 is the compact one (its G fragments, fetched by K-step KS - 3, come from `goffl`)
+template <int CT, int KS, int PEEL, bool LIGHT, int J>
 __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc Gw, const uint32_t (&goff)[3],
-                                        brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw, const uint32_t (&poff)[3]) {
+                                        const uint32_t (&goffl)[3], brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw,
+                                        const uint32_t (&poff)[3]) {
+  static_assert(PEEL >= 3, "the compact K-step's fragments are fetched inside the peeled part");
   if constexpr (J < PEEL) {
     constexpr int K = KS - PEEL + J, NQ = 3 * CT;
+    constexpr int MODE = !LIGHT ? RC_PLAIN : (K == KS - 3 ? RC_NEXT_LIGHT : (K == KS - 1 ? RC_LIGHT : RC_PLAIN));
     constexpr int NA = K + 2 < KS ? 3 : 0, NB = K + 1 < KS ? CT : 0;
     constexpr int PRE0 = J * NQ / PEEL, NPRE = (J + 1) * NQ / PEEL - PRE0;
     constexpr uint32_t WSTEP = 2u * CT * 1024u;
-    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), goff, Wf, (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw,
-                                            poff);
-    dr_peel<CT, KS, PEEL, J + 1>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
+    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf,
+                                                  (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
+    dr_peel<CT, KS, PEEL, LIGHT, J + 1>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   }
 }
 
 // one layer for the work-group's 96 rows (block index g); `red`: four floats of LDS
-template <int CT>
+template <int CT, bool LIGHT>
 __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red) {
   constexpr int NP = 32 * CT, NCT = 2 * CT, KS = NP / 16, NQ = 3 * CT;
   static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
@@ -136,11 +144,12 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
 
   // byte offsets of this lane's 16-byte pieces relative to the work-group's first row: G fragment of row tile rt (+ 64 ks),
   // and the accumulator quad of (rt, ct) in pre / out (+ 64 ct): row 48 wr + 16 rt + li, columns 16 (CT wc + ct) + 4 lq ..
-  uint32_t goff[3], poff[3], ooff[3];
+  uint32_t goff[3], goffl[3], poff[3], ooff[3];
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
     const int row = 48 * wr + 16 * rt + li;
     goff[rt] = (uint32_t)((row * a.ldg + 4 * lq) * 4);
+    goffl[rt] = (uint32_t)((row * a.ldg + lq) * 4);   // the compact K-step: k = 16 ks + lq
     poff[rt] = (uint32_t)((row * a.ldp + 16 * CT * wc + 4 * lq) * 4);
     ooff[rt] = (uint32_t)((row * a.ldo + 16 * CT * wc + 4 * lq) * 4);
   }
@@ -181,7 +190,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
     dr_kstep<CT, 3, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
   }
   DR_STAMP(2);
-  dr_peel<CT, KS, PEEL, 0>(acc, A, B, Gw, goff, Wf, lane16, pq, Pw, poff);
+  dr_peel<CT, KS, PEEL, LIGHT, 0>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   DR_STAMP(3);
   rc_acc_settle<CT>(acc);
   // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
@@ -218,10 +227,11 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
 }
 
 
-template <int CT>
+// LIGHT: the weight copy's last K-step is compact (elementwise.h: wfrag_index; the host picks the instantiation)
+template <int CT, bool LIGHT = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_rows(const DgradRowsArgs a) {
   __shared__ float red[4];
-  dr_layer<CT>(a, (int)blockIdx.x, red);
+  dr_layer<CT, LIGHT>(a, (int)blockIdx.x, red);
 }
 
 // The whole input-gradient chain of a train step in ONE launch: the loss value and the closed-form gradient seeds of the
@@ -236,7 +246,7 @@ struct DgradChainArgs {
   unsigned long long* seed_stamps;    // diagnostic builds only (-DDR_STAMPS): cycles of the seed stage per work-group
 };
 
-template <int CT>
+template <int CT, bool LIGHT = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_chain(const DgradChainArgs c) {
   __shared__ float red[4];
   __shared__ double shs[4], tot[4];
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_chain(const DgradChainArg
 #endif
   for (int l = 0; l < c.nlayers; ++l) {
     __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
-    dr_layer<CT>(c.layer[l], g, red);
+    dr_layer<CT, LIGHT>(c.layer[l], g, red);
   }
 }
 

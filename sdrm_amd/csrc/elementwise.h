@@ -574,13 +574,25 @@ struct Job {
   float* dstT; int dstT_ld;                                        // transposed compute copy [col][row] (may be null)
   float* dstF; float* dstFT; int fnct;                             // fragment-packed copies of the matrix / of its transpose for the
                                                                    // row-owned kernels (rowchain.h; may be null), fnct column tiles
+  int fklast, fklastT;                                             // their compact last K-step (wfrag_index), -1: none
 };
 
 // element (n, k) of a padded row-major [NP][KP] matrix in its fragment-packed copy (rowchain.h): [k / 16][n / 16][lane][k % 4],
 // lane = 16 * ((k / 4) % 4) + n % 16 - one contiguous 1 KiB wave-load per 16-column tile and 16-deep K-step
-__host__ __device__ inline size_t wfrag_index(int n, int k, int NCT) {
-  const int ct = n >> 4, nn = n & 15, ks = k >> 4, kg = (k >> 2) & 3, e = k & 3;
+// klast >= 0: K-step `klast` - the last one, when at most four of its sixteen k are real - is stored COMPACT: its k = 16 klast + j
+// sits in lane group j, component 0, so that ONE MFMA (the components 0 of the four lane groups) covers the four real k and the
+// K-step's other three MFMAs are not issued (rc_light_klast): 340 = 21 * 16 + 4 costs 85 k-groups of four instead of 88.
+__host__ __device__ inline size_t wfrag_index(int n, int k, int NCT, int klast = -1) {
+  const int ct = n >> 4, nn = n & 15, ks = k >> 4;
+  int kg = (k >> 2) & 3, e = k & 3;
+  if (ks == klast) { kg = k & 3; e = (k >> 2) & 3; }
   return ((((size_t)ks * NCT + ct) * 64) + (size_t)(kg * 16 + nn)) * 4 + e;
+}
+// the compact last K-step of a reduction axis of K real entries padded to KP: its index KP / 16 - 1, or -1 when that K-step
+// holds more than four real k (or none: a width whose padding spans a whole K-step keeps the plain layout)
+__host__ __device__ inline int rc_light_klast(int K, int KP) {
+  const int r = K - (KP - 16);
+  return (KP >= 32 && r >= 1 && r <= 4) ? KP / 16 - 1 : -1;
 }
 constexpr int MAX_JOBS = 12;
 struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
@@ -689,7 +701,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
         if (r < jb.rows && c < jb.cols) {
           w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
           if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
-          if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct)] = w;
+          if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct, jb.fklast)] = w;
         }
         tile[ty + 8 * k][tx] = w;
       }
@@ -699,7 +711,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
         const int c = c0 + ty + 8 * k, r = r0 + tx;
         if (r < jb.rows && c < jb.ncols) {
           jb.dstT[(size_t)c * jb.dstT_ld + r] = tile[tx][ty + 8 * k];
-          if (jb.dstFT != nullptr) jb.dstFT[wfrag_index(c, r, jb.fnct)] = tile[tx][ty + 8 * k];
+          if (jb.dstFT != nullptr) jb.dstFT[wfrag_index(c, r, jb.fnct, jb.fklastT)] = tile[tx][ty + 8 * k];
         }
       }
       __syncthreads();
@@ -711,7 +723,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
     const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
     const float w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
     if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
-    if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct)] = w;
+    if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct, jb.fklast)] = w;
   }
 }
 

@@ -64,6 +64,7 @@ struct RowChainArgs {
   // outputs, grouped stacked rows
   float* U; int K0, LPs; int* tdev;
   int ones_col;                             // pad column of U set to 1.0 in every row (-1: none), see wgrad2.h
+  int light;                                // the weight copies' last K-step is compact (wfrag_index): issue a quarter of its MFMAs
   float* pre; size_t pre_stride; int ldp;   // pre[k] = pre + k * pre_stride, [MP][ldp]
   float* act;                               // activations prelu(pre[k]) in the same layout (null: not stored)
   float* Y; int ldy;
@@ -182,18 +183,23 @@ __device__ __forceinline__ void rc_acc_settle(f32x4 (&acc)[3][CT]) {
 // slot, which pins it there.  STREAM = false: the tile is not stored (a layer whose input nobody reads again).
 // The MFMA operands are SWAPPED (weights as srcA, activations as srcB): the 16 x 16 tile comes out transposed, lane (li, lq)
 // holds row li, columns 4 lq .. 4 lq + 3 of it - every epilogue access is a 16-byte one.
-template <int CT, int LDA, int NS, bool STREAM, bool NT>
+// MODE (the compact last K-step of a layer, elementwise.h: wfrag_index): RC_NEXT_LIGHT - the A pieces fetch the NEXT K-step's
+// compact fragments (one float per lane: k = 16 ks + lane group; `anext` is that address); RC_LIGHT - this IS the compact K-step:
+// only the first MFMA of every tile is issued (its four lane groups hold the four real k), and nothing is fetched behind it.
+enum { RC_PLAIN = 0, RC_NEXT_LIGHT = 1, RC_LIGHT = 2 };
+template <int CT, int LDA, int NS, bool STREAM, bool NT, int MODE = RC_PLAIN>
 __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], const f32x4 (&bc)[CT], f32x4 (&an)[3],
                                          f32x4 (&bn)[CT], brsrc wres, uint32_t wnext, uint32_t lane16, uint32_t anext,
                                          const float* __restrict__ Act, brsrc sres, RcStream& sw) {
-  constexpr int NSLOT = 12 * CT;
-  constexpr int P_A = CT, P_S = CT + 3, NPIECE = P_S + (STREAM ? 2 * NS : 0);
-  constexpr int STRIDE = NSLOT / NPIECE >= RC_PIECE_STRIDE ? RC_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1);
+  constexpr int NE = MODE == RC_LIGHT ? 1 : 4;
+  constexpr int NSLOT = 3 * NE * CT;
+  constexpr int P_A = MODE == RC_LIGHT ? 0 : CT, P_S = MODE == RC_LIGHT ? 0 : CT + 3, NPIECE = P_S + (STREAM ? 2 * NS : 0);
+  constexpr int STRIDE = NPIECE == 0 ? NSLOT : (NSLOT / NPIECE >= RC_PIECE_STRIDE ? RC_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1));
   static_assert(NPIECE <= NSLOT && NS <= 2, "not enough MFMA slots for the pipeline pieces");
   f32x4 sv0 = {0.f, 0.f, 0.f, 0.f}, sv1 = sv0;
   uint32_t so0 = 0, so1 = 0;
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < NE; ++e)
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -216,7 +222,8 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
         if (!(RC_DIAG & 4)) {
           uint32_t ao = anext;
           asm volatile("" : "+v"(ao));
-          an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
+          if (MODE == RC_NEXT_LIGHT) an[p - P_A][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
+          else an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
         }
       } else {
         // tile stream, chunk q: LDS read, then (NS pieces later) the HBM store
@@ -258,7 +265,8 @@ __device__ __forceinline__ void block_sum4(double (&v)[4], double* sh /* [16] */
   for (int j = 0; j < 4; ++j) v[j] = (sh[j] + sh[4 + j]) + (sh[8 + j] + sh[12 + j]);
 }
 
-template <int CT>
+// LIGHT: the weight copies' last K-step is compact (a.light; the host picks the instantiation)
+template <int CT, bool LIGHT = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   typedef RowChainCfg<CT> C;
   constexpr int NP = C::NP, NCT = C::NCT, KS = C::KS, QP = C::QP, LDA = C::LDA, RT = 3;
@@ -382,6 +390,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   // lane (li, lq) holds of tile (rt, ct) row 32 rt + 16 wr + li, columns 16 (CT wc + ct) + 4 lq .. + 3 (the transposed MFMA tile)
   const float* abase = Act + (16 * wr + li) * LDA + 4 * lq;     // + 32 * rt * LDA + 16 * ks: A fragment reads
   const uint32_t aoff = (uint32_t)(((16 * wr + li) * LDA + 4 * lq) * 4);   // the same as a byte offset into the tile
+  const uint32_t aoffl = (uint32_t)(((16 * wr + li) * LDA + lq) * 4);      // ... of the compact K-step's fragment (k = 16 ks + lq)
   const uint32_t lane16 = 16u * (uint32_t)lane;   // byte offset of a lane's float4 in a 1 KiB wave-load
   const int myrow = 16 * wr + li;                 // + 32 rt: the lane's row of the tile; its user is u0 + myrow
   const int mycol = 16 * CT * wc + 4 * lq;        // + 16 ct: the first of its four columns
@@ -431,10 +440,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
     sw.template init<CT, LDA>(tid, sld);
     auto kloop = [&](auto stream_tag, auto nt_tag) {
       constexpr bool STREAM = decltype(stream_tag)::value, NT = decltype(nt_tag)::value;
-      for (uint32_t ks = 0; ks < (uint32_t)KS; ks += 2) {
-        const uint32_t k2 = ks + 2 < (uint32_t)KS ? ks + 2 : ks;   // past the end: a harmless re-read
-        rc_kstep<CT, LDA, 2, STREAM, NT>(acc, a0, b0, a1, b1, Wf, (ks + 1) * (uint32_t)(NCT * 1024), lane16, aoff + 64u * (ks + 1), Act, sres, sw);
-        rc_kstep<CT, LDA, 1, STREAM, NT>(acc, a1, b1, a0, b0, Wf, k2 * (uint32_t)(NCT * 1024), lane16, aoff + 64u * k2, Act, sres, sw);
+      constexpr uint32_t WS = NCT * 1024;
+      for (uint32_t ks = 0; ks < (uint32_t)KS - 2; ks += 2) {
+        rc_kstep<CT, LDA, 2, STREAM, NT>(acc, a0, b0, a1, b1, Wf, (ks + 1) * WS, lane16, aoff + 64u * (ks + 1), Act, sres, sw);
+        rc_kstep<CT, LDA, 1, STREAM, NT>(acc, a1, b1, a0, b0, Wf, (ks + 2) * WS, lane16, aoff + 64u * (ks + 2), Act, sres, sw);
+      }
+      // the last pair: K-step KS - 1 may be the compact one (a.light: four real k in its sixteen)
+      if constexpr (LIGHT) {
+        rc_kstep<CT, LDA, 2, STREAM, NT, RC_NEXT_LIGHT>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoffl + 64u * (KS - 1), Act, sres, sw);
+        rc_kstep<CT, LDA, 1, STREAM, NT, RC_LIGHT>(acc, a1, b1, a0, b0, Wf, 0u, lane16, aoff, Act, sres, sw);
+      } else {
+        rc_kstep<CT, LDA, 2, STREAM, NT>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoff + 64u * (KS - 1), Act, sres, sw);
+        rc_kstep<CT, LDA, 1, STREAM, NT>(acc, a1, b1, a0, b0, Wf, (KS - 2) * WS, lane16, aoff + 64u * (KS - 2), Act, sres, sw);   // past the end: a harmless re-read
       }
     };
     rc_acc_begin<CT>(acc);

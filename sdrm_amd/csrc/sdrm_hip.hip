@@ -432,27 +432,27 @@ void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad
     j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
     j.inner = inner;
     j.dstT = dstT; j.dstT_ld = dstT_ld;
-    j.dstF = nullptr; j.dstFT = nullptr; j.fnct = e->WP / 16;
+    j.dstF = nullptr; j.dstFT = nullptr; j.fnct = e->WP / 16; j.fklast = -1; j.fklastT = -1;
     j.gdst = gbase + off; j.g_ld = flat_ld;
   };
   // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
   add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
   add(e->off_w0, W, L + T, L + T, L, e->slab0, e->K0, (size_t)e->WP * e->K0, S0, e->W0c, e->K0);
-  tab.j[n - 1].dstF = e->W0f;
+  tab.j[n - 1].dstF = e->W0f; tab.j[n - 1].fklast = rc_light_klast(L, e->LP);
   if (bias_col >= 0) add(e->off_b0, W, 1, 1, 1, e->slab0 + bias_col, e->K0, (size_t)e->WP * e->K0, S0, e->b0c, 1);
   else add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
   // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
   add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
   if (H >= 1) {
     add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
-    tab.j[n - 1].dstF = e->Whf; tab.j[n - 1].dstFT = e->WhfT;
+    tab.j[n - 1].dstF = e->Whf; tab.j[n - 1].dstFT = e->WhfT; tab.j[n - 1].fklast = tab.j[n - 1].fklastT = rc_light_klast(W, e->WP);
     if (bias_col >= 0) add(e->off_bh, W, 1, 1, 1, e->slabH + bias_col, e->WP, (size_t)e->WP * e->WP, H * SH, e->bhc, 1);
     else add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
     add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
         dgrad_blocks);
   }
   add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
-  tab.j[n - 1].dstF = e->Wof; tab.j[n - 1].dstFT = e->WofT;
+  tab.j[n - 1].dstF = e->Wof; tab.j[n - 1].dstFT = e->WofT; tab.j[n - 1].fklast = rc_light_klast(W, e->WP); tab.j[n - 1].fklastT = rc_light_klast(L, e->LP);
   if (bias_col >= 0) add(e->off_bo, L, 1, 1, 1, e->slabO + bias_col, e->WP, (size_t)e->LP * e->WP, SO, e->boc, 1);
   else add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
   tab.n_adam = n;
@@ -580,7 +580,9 @@ int launch_dgrad_rows_ct(sdrm_engine* e, const DgradRowsArgs& a, int G, double f
     e->prof_flops.push_back(flops);
     HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
   }
-  SDRM_LAUNCH(e, (k_dgrad_rows<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  // (the weight copies' compact last K-step, elementwise.h: L == W on this path)
+  if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_dgrad_rows<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_dgrad_rows<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
   if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
@@ -621,7 +623,8 @@ int launch_dgrad_chain_ct(sdrm_engine* e, const DgradChainArgs& a, int G, double
     e->prof_flops.push_back(flops);
     HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
   }
-  SDRM_LAUNCH(e, (k_dgrad_chain<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_dgrad_chain<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_dgrad_chain<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
   if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
@@ -661,7 +664,8 @@ int launch_row_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStrea
     e->prof_flops.push_back(flops);
     HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
   }
-  SDRM_LAUNCH(e, (k_row_fwd<CT>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  if (a.light) SDRM_LAUNCH(e, (k_row_fwd<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_row_fwd<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
   if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
@@ -679,6 +683,7 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.W0f = e->W0f; a.Whf = e->Whf; a.Wof = e->Wof; a.bh = e->bhc; a.bo = e->boc; a.B0tab = e->B0tab; a.ldtab = e->WP;
   a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
   a.U = e->U; a.K0 = e->K0; a.LPs = e->LP; a.tdev = e->tdev; a.ones_col = e->ones_col;
+  a.light = rc_light_klast(e->W, e->WP) >= 0 ? 1 : 0;   // L == W on this path: one answer for every layer
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
   a.act = e->act;
   a.loss_part = e->loss_part;

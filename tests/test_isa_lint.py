@@ -82,9 +82,10 @@ VALU_OK_IN_LOOP = ("v_mfma",)
 
 @pytest.mark.parametrize("ct", [4, 11])
 def test_row_owned_kernels_isa(ct):
-    asm = _compile(f"template __global__ void sdrm::k_dgrad_chain<{ct}>(const sdrm::DgradChainArgs);\n"
-                   f"template __global__ void sdrm::k_dgrad_rows<{ct}>(const sdrm::DgradRowsArgs);\n"
-                   f"template __global__ void sdrm::k_row_fwd<{ct}>(const sdrm::RowChainArgs);\n")
+    light = "true" if ct == 11 else "false"   # the compact last K-step (340 = 21 * 16 + 4) on the headline width, plain on the other
+    asm = _compile(f"template __global__ void sdrm::k_dgrad_chain<{ct}, {light}>(const sdrm::DgradChainArgs);\n"
+                   f"template __global__ void sdrm::k_dgrad_rows<{ct}, {light}>(const sdrm::DgradRowsArgs);\n"
+                   f"template __global__ void sdrm::k_row_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n")
     ks = _kernels(asm)
     names = {"chain": [n for n in ks if "k_dgrad_chain" in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
              "fwd": [n for n in ks if "k_row_fwd" in n]}

@@ -53,7 +53,7 @@ int main(int argc, char** argv) {
       const float w = nrm(rng) * 0.05f;
       hW[(size_t)k * NP + n] = w;
       hWT[(size_t)n * NP + k] = w;                       // the NT kernel's operand: [n][k], k contiguous
-      hF[wfrag_index(n, k, NP / 16)] = w;
+      hF[wfrag_index(n, k, NP / 16, rc_light_klast(W, NP))] = w;   // W = NP - 12: the last K-step holds four real k - the compact form
     }
   const float slope = 0.25f;
   float *dG = dalloc<float>(hG.size()), *dP = dalloc<float>(hP.size()), *dWT = dalloc<float>(hWT.size()), *dF = dalloc<float>(hF.size());
@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
   DgradRowsArgs a{};
   a.G = dG; a.ldg = NP; a.WfT = dF; a.pre = dP; a.ldp = NP; a.slope = dS; a.out = dO; a.ldo = NP; a.slope_part = dpart;
   const int grid = MP / RC_ROWS;
-  auto launch_new = [&]() { hipLaunchKernelGGL((k_dgrad_rows<CT>), dim3(grid), dim3(NTHREADS), 0, 0, a); };
+  auto launch_new = [&]() { hipLaunchKernelGGL((k_dgrad_rows<CT, true>), dim3(grid), dim3(NTHREADS), 0, 0, a); };
 
   GemmArgs g{};
   g.A = dG; g.lda = NP; g.limA = MP; g.B = dWT; g.ldb = NP; g.limB = NP; g.C = dO2; g.ldc = NP; g.K = NP; g.kchunk = NP;
@@ -160,7 +160,7 @@ int main(int argc, char** argv) {
     ch.layer[0] = a; ch.layer[0].out = dG1;
     ch.layer[1] = a; ch.layer[1].G = dG1; ch.layer[1].out = dO; ch.layer[1].slope_part = dpart + 4096;
   }
-  auto launch_chain = [&]() { hipLaunchKernelGGL((k_dgrad_chain<CT>), dim3(grid), dim3(NTHREADS), 0, 0, ch); };
+  auto launch_chain = [&]() { hipLaunchKernelGGL((k_dgrad_chain<CT, true>), dim3(grid), dim3(NTHREADS), 0, 0, ch); };
 #ifdef DR_STAMPS
   {
     unsigned long long* dss = dalloc<unsigned long long>(grid);

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
       for (int k = 0; k < L; ++k) hW[l][(size_t)n * NP + k] = uni(rng) * sc[l];
     hWf[l].assign((size_t)NP * NP, 0.f);
     for (int n = 0; n < NP; ++n)
-      for (int k = 0; k < NP; ++k) hWf[l][wfrag_index(n, k, NCT)] = hW[l][(size_t)n * NP + k];
+      for (int k = 0; k < NP; ++k) hWf[l][wfrag_index(n, k, NCT, rc_light_klast(L, NP))] = hW[l][(size_t)n * NP + k];   // compact last K-step
   }
   std::vector<float> hB0tab((size_t)(T + 1) * NP, 0.f), hbh(NP, 0.f), hbo(NP, 0.f);
   for (int t = 0; t <= T; ++t) for (int n = 0; n < W; ++n) hB0tab[(size_t)t * NP + n] = uni(rng) * 0.1f;
@@ -103,13 +103,13 @@ int main(int argc, char** argv) {
   a.W0f = dWf[0]; a.Whf = dWf[1]; a.Wof = dWf[2]; a.bh = dbh; a.bo = dbo; a.B0tab = dB0tab; a.ldtab = NP;
   a.slope0 = dsl; a.slopeh = dsl + 1;
   a.U = dU; a.K0 = K0; a.LPs = NP; a.tdev = dtdev; a.pre = dpre; a.pre_stride = (size_t)MP * NP; a.ldp = NP; a.Y = dY; a.ldy = NP;
-  a.loss_part = dpart; a.act = dact; a.ones_col = -1;
+  a.loss_part = dpart; a.act = dact; a.ones_col = -1; a.light = 1;
 
   auto launch_row = [&](int mode) {
     RowChainArgs b = a;
     b.mode = mode;
     if (mode) { b.noise = nullptr; b.t = nullptr; b.keep = nullptr; }
-    hipLaunchKernelGGL((k_row_fwd<CT>), dim3(G), dim3(NTHREADS), 0, 0, b);
+    hipLaunchKernelGGL((k_row_fwd<CT, true>), dim3(G), dim3(NTHREADS), 0, 0, b);
   };
   // the per-layer path's three NT launches on the same shapes (inputs: whatever the row kernel left in U / pre)
   auto launch_layers = [&]() {
@@ -216,7 +216,7 @@ int main(int argc, char** argv) {
     unsigned long long* dst = dalloc<unsigned long long>((size_t)16 * G);
     RowChainArgs b = a;
     b.mode = 1; b.noise = nullptr; b.t = nullptr; b.keep = nullptr; b.stamps = dst;
-    for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((k_row_fwd<CT>), dim3(G), dim3(NTHREADS), 0, 0, b);
+    for (int k = 0; k < 20; ++k) hipLaunchKernelGGL((k_row_fwd<CT, true>), dim3(G), dim3(NTHREADS), 0, 0, b);
     CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> hs((size_t)16 * G);
     CHECK(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
