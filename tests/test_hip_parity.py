@@ -386,7 +386,10 @@ def test_weight_gradients_at_any_slice_count(engine_cls, monkeypatch, dims, slic
                                   # every padded width of the row-owned kernels' envelope (6 .. 10 column tiles of 32: each has its own
                                   # instantiation, and its own split of the K loop into trips and peeled K-steps)
                                   (180, 180, 9, 1, 40), (200, 200, 9, 1, 40), (250, 250, 20, 1, 70), (280, 280, 6, 2, 33),
-                                  (310, 310, 6, 1, 33)])
+                                  (310, 310, 6, 1, 33),
+                                  # widths that are no multiple of four (rows of x0 not 16-byte aligned; 337: one real k in the compact last
+                                  # K-step, the last user's last column quad ends with the buffer)
+                                  (337, 337, 6, 1, 33), (130, 130, 9, 1, 64)])
 def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
     """Behind the row-owned forward (grouped row order, stored activations, ones column) the three backward forms must agree:
     one call with the strip-owned weight gradients (bias gradients from the ones column of the slabs), one call with the
