@@ -146,3 +146,51 @@ def test_row_owned_kernels_isa(ct):
         for i in mf:
             if not ins[i + 1].startswith("v_mfma"):
                 walk(i + 1, 0, 96, set())
+
+
+def test_fragment_packing_is_a_bijection():
+    """wfrag_index (csrc/elementwise.h) maps the (n, k) of a padded [NP][KP] weight onto the fragment-packed copy the row-owned
+    kernels load from - with the compact last K-step (k = 16 klast + j in lane group j, component 0) it must still hit every
+    slot exactly once, and rc_light_klast must pick that form exactly when the last padded K-step holds one to four real k.
+    Host code, compiled with hipcc and run here."""
+    src = r'''
+#include <cstdio>
+#include <vector>
+#include "%s/elementwise.h"
+using namespace sdrm;
+int main() {
+  const int cases[][3] = {{340, 352, 21}, {337, 352, 21}, {180, 192, 11}, {100, 128, -1}, {136, 160, -1}, {352, 352, -1}, {341, 352, -1},
+                          {336, 352, -1}, {20, 32, 1}, {16, 32, -1}};
+  for (auto& c : cases) {
+    const int K = c[0], KP = c[1], want = c[2];
+    const int kl = rc_light_klast(K, KP);
+    if (kl != want) { printf("rc_light_klast(%%d, %%d) = %%d, expected %%d\n", K, KP, kl, want); return 1; }
+    const int NP = KP, NCT = NP / 16;
+    std::vector<int> hit((size_t)NP * KP, 0);
+    for (int n = 0; n < NP; ++n)
+      for (int k = 0; k < KP; ++k) {
+        const size_t i = wfrag_index(n, k, NCT, kl);
+        if (i >= hit.size()) { printf("index out of range\n"); return 1; }
+        ++hit[i];
+        // the layout contract of the kernels: tile (k / 16, n / 16) is 256 consecutive floats, lane = 16 * group + n %% 16
+        const size_t tile = i / 256, lane = (i %% 256) / 4, comp = i %% 4;
+        const int kk = k & 15;
+        const bool compact = (k >> 4) == kl;
+        const int group = compact ? (kk & 3) : (kk >> 2), e = compact ? (kk >> 2) : (kk & 3);
+        if (tile != (size_t)(k >> 4) * NCT + (n >> 4) || lane != (size_t)(16 * group + (n & 15)) || comp != (size_t)e) { printf("layout\n"); return 1; }
+      }
+    for (int v : hit) if (v != 1) { printf("not a bijection at K = %%d\n", K); return 1; }
+  }
+  printf("ok\n");
+  return 0;
+}
+''' % CSRC
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "h.hip")
+        with open(path, "w") as f:
+            f.write(src)
+        exe = os.path.join(d, "h")
+        res = subprocess.run([_hipcc(), "-O1", "-std=c++17", "--offload-arch=gfx950", "-o", exe, path], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
