@@ -165,12 +165,14 @@ __device__ __forceinline__ void tile_offsets(int ld, uint32_t (&vo)[ROWS * BK / 
     }
   }
 }
+// The resource starts at the work-group's own corner of the operand - first row / column of its tile AND first k of its K range
+// (64-bit arithmetic, once) - so the 32-bit offsets behind it only span one tile x one K chunk, whatever the operand's size.
 template <int LOAD, int ROWS, int BK>
-__device__ __forceinline__ brsrc tile_resource(const float* __restrict__ src, int ld, int i0) {
-  return make_brsrc(LOAD == LD_KCONTIG ? src + (size_t)i0 * ld : src + i0, 0xffffffffu);
+__device__ __forceinline__ brsrc tile_resource(const float* __restrict__ src, int ld, int i0, int kb) {
+  return make_brsrc(LOAD == LD_KCONTIG ? src + (size_t)i0 * ld + kb : src + (size_t)kb * ld + i0, 0xffffffffu);
 }
 template <int LOAD, int ROWS, int BK>
-__device__ __forceinline__ void load_tile(brsrc res, const uint32_t (&vo)[ROWS * BK / 4 / NTHREADS], int ld, int k0,
+__device__ __forceinline__ void load_tile(brsrc res, const uint32_t (&vo)[ROWS * BK / 4 / NTHREADS], int ld, int k0 /* from the resource's first k */,
                                           float4 (&r)[ROWS * BK / 4 / NTHREADS]) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
   const uint32_t so = (LOAD == LD_KCONTIG ? (uint32_t)k0 : (uint32_t)k0 * (uint32_t)ld) * 4u;
@@ -361,14 +363,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   const int aoff = lhi * LDA + wm * (BM / Cfg::WM) + l31;
   const int boff = lhi * LDB + wn * (BN / Cfg::WN) + l31;
 
-  const brsrc resA = tile_resource<LOADA, BM, BK>(p.A, p.lda, m0), resB = tile_resource<LOADB, BN, BK>(p.B, p.ldb, n0);
+  const brsrc resA = tile_resource<LOADA, BM, BK>(p.A, p.lda, m0, kb), resB = tile_resource<LOADB, BN, BK>(p.B, p.ldb, n0, kb);
   uint32_t voA[NVA], voB[NVB];
   tile_offsets<LOADA, BM, BK>(p.lda, voA, tid);
   tile_offsets<LOADB, BN, BK>(p.ldb, voB, tid);
   auto ld = [&](float4 (&xa)[NVA], float4 (&xb)[NVB], int i) {
     const int k0 = kb + min(i, nt - 1) * BK;   // past the end: re-read the last K-step (never consumed)
-    load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa);
-    load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb);
+    load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa);
+    load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb);
   };
   auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
     float* An = smem + stage * Cfg::STAGE;
@@ -496,9 +498,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
           if constexpr (XFA == XF_PRELU) DIAG_ST((store_tile_km<XF_NONE, BM, LDK, BK>(Aw, xa, 0.f, tid)));
           DIAG_ST((store_tile_km<XFB, BN, LDK, BK>(Aw + BOFF, xb, slopeB, tid)));
         } else if (sl == 2 * NQ + 2) {
-          DIAG_LD((load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa)));
+          DIAG_LD((load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa)));
         } else if (sl == 2 * NQ + 3) {
-          DIAG_LD((load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb)));
+          DIAG_LD((load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb)));
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -595,8 +597,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         }
         if (g == G / 2) store_tile<LOADA, XFA, BM, LDA, BK>(Aw, xa, slopeA, tid);
         else if (g == G / 2 + 1) store_tile<LOADB, XFB, BN, LDB, BK>(Aw + BOFF, xb, slopeB, tid);
-        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0, xa);
-        else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0, xb);
+        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa);
+        else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb);
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();

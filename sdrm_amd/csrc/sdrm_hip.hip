@@ -259,6 +259,13 @@ template <class Cfg, int LA, int LB, int XA, int XB, int EPI>
 hipError_t launch_gemm_cfg(GemmArgs& a, int M, int N, int splits, hipStream_t st, Prof pr) {
   const int tiles_m = (M + Cfg::BM - 1) / Cfg::BM, tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
   if (!gemm_set_grid(a, tiles_m, tiles_n, splits)) return hipErrorInvalidValue;   // beyond the exact range of the magic divisions
+  // the tile loads address one tile x one K chunk with 32-bit offsets behind a 64-bit base (gemm.h: tile_resource)
+  {
+    const uint64_t kc = (uint64_t)std::max(a.kchunk, 1) + 64;
+    const uint64_t spanA = LA == LD_KCONTIG ? ((uint64_t)Cfg::BM * a.lda + kc) : kc * a.lda;
+    const uint64_t spanB = LB == LD_KCONTIG ? ((uint64_t)Cfg::BN * a.ldb + kc) : kc * a.ldb;
+    if (spanA * 4 >= (1ull << 32) || spanB * 4 >= (1ull << 32)) return hipErrorInvalidValue;
+  }
   dim3 grid(EPI == EPI_SLAB ? (unsigned)(a.nblocks * splits) : (unsigned)a.nblocks, 1, 1);
   sdrm_engine* e = pr.e;
   const bool rec = e && e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == pr.cls);
@@ -353,6 +360,8 @@ hipError_t launch_wgrad_batch(sdrm_engine* e, const WgradSpec* w, int n, int Mro
     a.dbias = w[k].dbias; a.dbias_stride = w[k].Nout;
     const int tiles_m = (w[k].Nout + Cfg0::BM - 1) / Cfg0::BM, tiles_n = (w[k].Kin + Cfg0::BN - 1) / Cfg0::BN;
     if (!gemm_set_grid(a, tiles_m, tiles_n, w[k].S)) return hipErrorInvalidValue;
+    // 32-bit offsets inside one K chunk (gemm.h: tile_resource): both operands are M-contiguous here
+    if (((uint64_t)std::max(a.kchunk, 1) + 64) * (uint64_t)std::max(a.lda, a.ldb) * 4 >= (1ull << 32)) return hipErrorInvalidValue;
     b.start[k] = grid;
 #ifdef SDRM_STAMPS
     a.stamps = (g_wgrad_stamps && g_stamp_class < 0) ? g_wgrad_stamps + 8 * (size_t)grid : nullptr;

@@ -102,8 +102,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_wgrad_strips(const Wg2Args a) {
   // operands through raw buffer resources (bufres.h): per-lane offsets fixed for the whole launch, the row block as a SCALAR
   // offset - a global_load's 64-bit address would be two VALU instructions per load, and with one wave per SIMD a VALU
   // instruction and the load that waits for it stall the MFMA stream (csrc/dgrad_rows.h)
+  // (the resources start at the work-group's own K slice - 64-bit arithmetic, once - so the 32-bit offsets behind them span one
+  // slice whatever the batch size)
   const int lda_a = Pa.lda, lda_b = Pb.lda;
-  const brsrc Ra = make_brsrc(Pa.A, (uint32_t)a.rows * (uint32_t)lda_a * 4u), Rb = make_brsrc(Pb.A, (uint32_t)a.rows * (uint32_t)lda_b * 4u);
+  auto span = [&](int ld, int skip) __attribute__((always_inline)) {   // bytes from the slice's first row to the operand's end
+    const size_t b = ((size_t)(a.rows - m_begin) * (size_t)ld - (size_t)skip) * 4;
+    return (uint32_t)(b < 0xffffffffull ? b : 0xffffffffull);
+  };
+  const brsrc Ra = make_brsrc(Pa.A + (size_t)m_begin * lda_a, span(lda_a, 0)), Rb = make_brsrc(Pb.A + (size_t)m_begin * lda_b, span(lda_b, 0));
   // the B block this thread stages for j = 0, 1: strip (wave >> 1) + 2 j of the unit (idle strips repeat the first problem)
   brsrc RB0, RB1; int Bld[2];
   {
@@ -111,8 +117,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_wgrad_strips(const Wg2Args a) {
     const Wg2Problem P0 = wg2_problem(a, s0.problem < 0 ? pa : s0.problem), P1 = wg2_problem(a, s1.problem < 0 ? pa : s1.problem);
     Bld[0] = P0.ldb; Bld[1] = P1.ldb;
     const int c0 = 32 * (s0.problem < 0 ? 0 : s0.ktile), c1 = 32 * (s1.problem < 0 ? 0 : s1.ktile);
-    RB0 = make_brsrc(P0.B + c0, ((uint32_t)a.rows * (uint32_t)P0.ldb - (uint32_t)c0) * 4u);
-    RB1 = make_brsrc(P1.B + c1, ((uint32_t)a.rows * (uint32_t)P1.ldb - (uint32_t)c1) * 4u);
+    RB0 = make_brsrc(P0.B + (size_t)m_begin * P0.ldb + c0, span(P0.ldb, c0));
+    RB1 = make_brsrc(P1.B + (size_t)m_begin * P1.ldb + c1, span(P1.ldb, c1));
   }
   // Operands stream from HBM and one work-group per CU has few loads in flight: the loads of a K-step are requested THREE steps
   // before they are stored to LDS (three register sets in rotation).  With one wave per SIMD every memory instruction's issue time
@@ -149,10 +155,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_wgrad_strips(const Wg2Args a) {
   auto gload_piece = [&](auto two_tag, RSet& r, int m0, int k) __attribute__((always_inline)) {
     constexpr bool TWO = decltype(two_tag)::value;
     constexpr int NA = TWO ? 2 * C::NLA : C::NLA;
-    if (k < C::NLA) r.a[k] = as4(bload4(Ra, voA[k], (uint32_t)(m0 * lda_a) * 4u));
-    else if (TWO && k < NA) r.a2[k - C::NLA] = as4(bload4(Rb, voA2[k - C::NLA], (uint32_t)(m0 * lda_b) * 4u));
-    else if (k == NA) r.b[0] = as4(bload4(RB0, voB[0], (uint32_t)(m0 * Bld[0]) * 4u));
-    else if (k == NA + 1) r.b[1] = as4(bload4(RB1, voB[1], (uint32_t)(m0 * Bld[1]) * 4u));
+    if (k < C::NLA) r.a[k] = as4(bload4(Ra, voA[k], (uint32_t)((m0 - m_begin) * lda_a) * 4u));
+    else if (TWO && k < NA) r.a2[k - C::NLA] = as4(bload4(Rb, voA2[k - C::NLA], (uint32_t)((m0 - m_begin) * lda_b) * 4u));
+    else if (k == NA) r.b[0] = as4(bload4(RB0, voB[0], (uint32_t)((m0 - m_begin) * Bld[0]) * 4u));
+    else if (k == NA + 1) r.b[1] = as4(bload4(RB1, voB[1], (uint32_t)((m0 - m_begin) * Bld[1]) * 4u));
   };
   auto lstore_piece = [&](auto two_tag, const RSet& r, float* S, int k) __attribute__((always_inline)) {
     constexpr bool TWO = decltype(two_tag)::value;

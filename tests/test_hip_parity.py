@@ -102,6 +102,29 @@ def test_mfma_gemm_variants(engine_cls, variant, shape, tile):
     assert rel_max(got, ref32) < 2e-6, rel_max(got, ref32)
 
 
+def test_gemm_operand_beyond_4_gib(engine_cls):
+    """The tile loads are raw buffer loads with 32-bit offsets behind a 64-bit base at the work-group's own tile and K chunk
+    (csrc/gemm.h: tile_resource): an operand of more than 4 GiB must come out right in its last rows too."""
+    from sdrm_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    M, N, K = 3_276_800, 64, 352          # A: 4.6 GB
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    dA = torch.randn((M, K), dtype=torch.float32, device="cuda", generator=gen)
+    dB = torch.randn((N, K), dtype=torch.float32, device="cuda", generator=gen)
+    dC = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.sdrm_debug_gemm(0, 0, C.c_void_p(dA.data_ptr()), C.c_void_p(dB.data_ptr()), C.c_void_p(dC.data_ptr()), M, N, K,
+                             C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for lo in (0, (1 << 32) // (4 * K) - 64, M - 128):      # first rows, the rows around the 4 GiB line, the last rows
+        ref = dA[lo:lo + 128].double() @ dB.double().T
+        got = dC[lo:lo + 128].double()
+        assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), lo
+    del dA, dC
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("T", [3, 8, 78, 83, 93, 198])
 def test_schedule_golden(engine_cls, golden, T):
     g = golden("schedule")
