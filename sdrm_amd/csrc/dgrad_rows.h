@@ -300,27 +300,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_dgrad_chain(const DgradChainArg
     for (int j = 0; j < CT; ++j) {
       const int col = 4 * (sq + 8 * j);
       const size_t yP = rowP * a.LP + col, yS = yP + (size_t)RC_USERS * a.LP, yQ = yS + (size_t)RC_USERS * a.LP;
-      float gP[4] = {0.f, 0.f, 0.f, 0.f}, gS[4] = {0.f, 0.f, 0.f, 0.f}, gQ[4] = {0.f, 0.f, 0.f, 0.f};
+      // four columns at a time as vector arithmetic: the compiler pairs it into v_pk_mul / v_pk_add / v_pk_fma (two elements per
+      // instruction) - with one wave per SIMD this stage is as much VALU time as memory time.
+      // 1 / mu^2 as a multiply (as the forward's loss sums do): an IEEE division is ten instructions, three of them per element
+      // made this stage 41 k cycles of the launch
+      f32x4 gP = {0.f, 0.f, 0.f, 0.f}, gS = gP, gQ = gP;
       if (r < a.B && col < a.L) {
-        const float p_[4] = {P4[j].x, P4[j].y, P4[j].z, P4[j].w}, s_[4] = {S4[j].x, S4[j].y, S4[j].z, S4[j].w},
-                    q_[4] = {Q4[j].x, Q4[j].y, Q4[j].z, Q4[j].w}, x_[4] = {X4[j].x, X4[j].y, X4[j].z, X4[j].w};
+        const f32x4 P = {P4[j].x, P4[j].y, P4[j].z, P4[j].w}, S = {S4[j].x, S4[j].y, S4[j].z, S4[j].w},
+                    Q = {Q4[j].x, Q4[j].y, Q4[j].z, Q4[j].w}, X = {X4[j].x, X4[j].y, X4[j].z, X4[j].w};
+        const f32x4 R = P - X;
+        const f32x4 D = (Q - S) * (1.f / MU2) - R;
+        const f32x4 gD = cD * D;
+        const f32x4 gC = cD * (R - S);
+        const f32x4 gV = cV * (R - rbar);
+        const f32x4 gDm = gD * (1.f / MU2);
+        gP = (-gD + gC + gV) * (1.f - P * P);
+        gQ = gDm * (1.f - Q * Q);
+        gS = (-gDm - gC) * (1.f - S * S);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (col + i < a.L) {
-            const float P = p_[i], S = s_[i], Q = q_[i];
-            const float R = P - x_[i];
-            // 1 / mu^2 as a multiply (as the forward's loss sums do): an IEEE division is ten instructions, three of them per
-            // element made this stage 41 k cycles of the launch - one wave per SIMD has no second wave to hide them behind
-            const float D = (Q - S) * (1.f / MU2) - R;
-            const float gD = cD * D;
-            const float gC = cD * (R - S);
-            const float gV = cV * (R - rbar);
-            const float gDm = gD * (1.f / MU2);
-            gP[i] = (-gD + gC + gV) * (1.f - P * P);
-            gQ[i] = gDm * (1.f - Q * Q);
-            gS[i] = (-gDm - gC) * (1.f - S * S);
-          }
-        }
+        for (int i = 1; i < 4; ++i)
+          if (col + i >= a.L) { gP[i] = 0.f; gQ[i] = 0.f; gS[i] = 0.f; }
       }
       *reinterpret_cast<float4*>(a.dY + yP) = make_float4(gP[0], gP[1], gP[2], gP[3]);
       *reinterpret_cast<float4*>(a.dY + yS) = make_float4(gS[0], gS[1], gS[2], gS[3]);
