@@ -313,6 +313,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   }
   __syncthreads();
   {
+    // one-hot(t) columns of U (read by the layer-0 weight gradient only; rows of users beyond the batch stay all-zero): the P, S
+    // and Q row of this thread's user, column quads sq + 8 j - issued first, they drain while the randoms are drawn
+    const int TQ8 = (a.K0 - a.LPs) >> 5;   // groups of eight quads (the one-hot block is a multiple of 32 columns wide)
+    const int tt = (susr < a.B) ? trow[su] : -1;
+    const brsrc ures = make_brsrc(a.U + grow0 * a.K0, (uint32_t)(RC_ROWS * a.K0 * 4));
+    const uint32_t uvo = (uint32_t)((su * a.K0 + a.LPs + 4 * sq) * 4);
+    for (int jq = 0; jq < TQ8; ++jq) {
+      const int h = 4 * (sq + 8 * jq);
+      const f32x4 oh = {h == tt ? 1.f : 0.f, h + 1 == tt ? 1.f : 0.f, h + 2 == tt ? 1.f : 0.f, h + 3 == tt ? 1.f : 0.f};
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) bstore4<true>(ures, uvo, (uint32_t)((pass * RC_USERS * a.K0 + 32 * jq) * 4), oh);
+    }
+  }
+  {
     const int tt = trow[su];
     const float sa = a.sqrt_ab[tt], om = a.one_minus_ab[tt];
     // PHILOX mode: the thread's NQ calls (one per column quad: two normal pairs and, in the low bits of word j, the three keep
@@ -369,17 +383,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
       *reinterpret_cast<float4*>(Act + su * LDA + c) = make_float4(vP[0], vP[1], vP[2], vP[3]);
       *reinterpret_cast<float4*>(Act + (RC_USERS + su) * LDA + c) = make_float4(vS[0], vS[1], vS[2], vS[3]);
       *reinterpret_cast<float4*>(Act + (2 * RC_USERS + su) * LDA + c) = make_float4(vQ[0], vQ[1], vQ[2], vQ[3]);
-    }
-  }
-  {
-    // one-hot(t) columns of U (read by the layer-0 weight gradient only); rows of users beyond the batch stay all-zero
-    const int TQ = (a.K0 - a.LPs) >> 2;
-    for (int f = tid; f < RC_ROWS * TQ; f += NTHREADS) {
-      const int row = f / TQ, h = 4 * (f - row * TQ);
-      const int u = row & (RC_USERS - 1);
-      const int tt = (u0 + u < a.B) ? trow[u] : -1;
-      *reinterpret_cast<float4*>(a.U + (grow0 + row) * a.K0 + a.LPs + h) =
-          make_float4(h == tt ? 1.f : 0.f, h + 1 == tt ? 1.f : 0.f, h + 2 == tt ? 1.f : 0.f, h + 3 == tt ? 1.f : 0.f);
     }
   }
   __syncthreads();

@@ -561,8 +561,9 @@ EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
   return a;
 }
 
-int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st) {
-  const EmbTabArgs a = emb_args(e, for_sampling);
+int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st, const float* warm = nullptr, size_t warm_floats = 0) {
+  EmbTabArgs a = emb_args(e, for_sampling);
+  a.warm = warm; a.warm_lines = warm ? (unsigned)std::min<size_t>(warm_floats / 32, 1u << 24) : 0u;
   SDRM_LAUNCH(e, k_emb_tables, dim3(e->T + 1), dim3(1024), 2 * e->T * sizeof(float), st, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
@@ -1181,8 +1182,9 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
 
   e->cur_grouped = false; e->cur_act = false;
   if (use_rowchain(e, B)) {
-    // row-owned forward (rowchain.h): the step's tables, then staging + every layer + the loss partial sums in ONE launch
-    int rc = emb_tables(e, true, st);
+    // row-owned forward (rowchain.h): the step's tables (the launch also pulls the batch into L2), then staging + every layer +
+    // the loss partial sums in ONE launch
+    int rc = emb_tables(e, true, st, x0, (size_t)B * e->L);
     if (rc) return rc;
     const int G = (B + RC_USERS - 1) / RC_USERS, MPg = round_up(G * RC_ROWS, BM);
     rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st);
