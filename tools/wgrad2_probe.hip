@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../sdrm_amd/csrc/wgrad2.h"
+#include "wgrad_strips16_experiment.h"
 
 using namespace sdrm;
 
@@ -73,6 +74,23 @@ int main(int argc, char** argv) {
   printf("# %d rows: %d strips in %d units x %d slices of %d rows = %d work-groups (grid %d), LDS %zu B\n", MP, ktiles[0] + ktiles[1] + ktiles[2],
          units, slices, kchunk, units * slices, grid, Wg2Cfg<NT>::LDS_BYTES);
   auto launch_new = [&]() { hipLaunchKernelGGL((k_wgrad_strips<NT>), dim3(grid), dim3(NTHREADS), 0, 0, a); };
+  // the 16-wide strips: twice the units, half the slices (slabs of their own)
+  Wg2Args a16{};
+  float* dslab16[3];
+  int ktiles16[3];
+  for (int p = 0; p < 3; ++p) {
+    dslab16[p] = dalloc<float>((size_t)64 * WP * ldb[p]);
+    a16.p[p] = a.p[p]; a16.p[p].slab = dslab16[p];
+    ktiles16[p] = ldb[p] / 16;
+  }
+  const int units16 = wg2_plan(ktiles16, 3, a16);
+  const int S16 = 256 / units16;
+  const int kchunk16 = round_up((MP + S16 - 1) / S16, WG2_BK);
+  const int slices16 = (MP + kchunk16 - 1) / kchunk16;
+  a16.slices = slices16; a16.rows = MP; a16.kchunk = kchunk16;
+  const int grid16 = units16 * slices16;
+  printf("# 16-wide strips: %d units x %d slices of %d rows = %d work-groups, LDS %zu B\n", units16, slices16, kchunk16, grid16, Wg2Cfg16<2 * NT>::LDS_BYTES);
+  auto launch_16 = [&]() { hipLaunchKernelGGL((k_wgrad_strips16<2 * NT>), dim3(grid16), dim3(NTHREADS), 0, 0, a16); };
 
   // the engine's batched launch on the same operands (24 slices of 1024 rows)
   GemmBatch gb{};
@@ -94,35 +112,40 @@ int main(int argc, char** argv) {
   };
 
   launch_new();
+  launch_16();
   launch_old();
   CHECK(hipGetLastError());
   CHECK(hipDeviceSynchronize());
   // sampled outputs: sum over slices of the slabs against fp64 on the host
-  double worst = 0, worst_old = 0, ref_max = 0;
+  double worst = 0, worst_old = 0, worst16 = 0, ref_max = 0;
   for (int p = 0; p < 3; ++p) {
-    std::vector<float> hs((size_t)slices * WP * ldb[p]), ho((size_t)((MP + kc_old - 1) / kc_old) * WP * ldb[p]);
+    std::vector<float> hs((size_t)slices * WP * ldb[p]), ho((size_t)((MP + kc_old - 1) / kc_old) * WP * ldb[p]), h16((size_t)slices16 * WP * ldb[p]);
     CHECK(hipMemcpy(hs.data(), dslab[p], hs.size() * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(h16.data(), dslab16[p], h16.size() * 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(ho.data(), dslab_old[p], ho.size() * 4, hipMemcpyDeviceToHost));
     for (int smp = 0; smp < 400; ++smp) {
       const int n = (int)(rng() % WP), k = (int)(rng() % ldb[p]);
       double ref = 0;
       for (int m = 0; m < MP; ++m) ref += (double)hA[p][(size_t)m * WP + n] * (double)hB[p][(size_t)m * ldb[p] + k];
-      double got = 0, old = 0;
+      double got = 0, old = 0, g16 = 0;
       for (int s = 0; s < slices; ++s) got += hs[(size_t)s * WP * ldb[p] + (size_t)n * ldb[p] + k];
+      for (int s = 0; s < slices16; ++s) g16 += h16[(size_t)s * WP * ldb[p] + (size_t)n * ldb[p] + k];
+      worst16 = std::max(worst16, std::fabs(g16 - ref));
       for (int s = 0; s < (MP + kc_old - 1) / kc_old; ++s) old += ho[(size_t)s * WP * ldb[p] + (size_t)n * ldb[p] + k];
       worst = std::max(worst, std::fabs(got - ref)); worst_old = std::max(worst_old, std::fabs(old - ref));
       ref_max = std::max(ref_max, std::fabs(ref));
     }
   }
-  const bool ok = worst <= 1e-5 * ref_max;
-  printf("max|err| over 1200 sampled outputs: strips %.3e, 64x64 batch %.3e (max|ref| %.3e): %s\n", worst, worst_old, ref_max, ok ? "OK" : "FAILED");
+  const bool ok = worst <= 1e-5 * ref_max && worst16 <= 1e-5 * ref_max;
+  printf("max|err| over 1200 sampled outputs: strips %.3e, 16-wide strips %.3e, 64x64 batch %.3e (max|ref| %.3e): %s\n", worst, worst16, worst_old, ref_max,
+         ok ? "OK" : "FAILED");
 
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-  std::vector<float> us[2];
+  std::vector<float> us[3];
   for (int r = 0; r < 7; ++r)
-    for (int v = 0; v < 2; ++v) {
-      auto go = [&]() { if (v == 0) launch_new(); else launch_old(); };
+    for (int v = 0; v < 3; ++v) {
+      auto go = [&]() { if (v == 0) launch_new(); else if (v == 1) launch_old(); else launch_16(); };
       go();
       CHECK(hipEventRecord(e0, 0));
       for (int k = 0; k < 20; ++k) go();
@@ -133,8 +156,8 @@ int main(int argc, char** argv) {
       us[v].push_back(ms * 1e3f / 20);
     }
   const double fl = 2.0 * MP * (340.0 * 418 + 340.0 * 340 + 340.0 * 340);
-  const char* names[2] = {"strip-owned (one work-group per CU)", "64x64 tiles, batched (the engine's)"};
-  for (int v = 0; v < 2; ++v) {
+  const char* names[3] = {"strip-owned (one work-group per CU)", "64x64 tiles, batched (the engine's)", "strip-owned, 16-wide strips"};
+  for (int v = 0; v < 3; ++v) {
     std::sort(us[v].begin(), us[v].end());
     printf("%-40s med %7.2f us  min %7.2f us  (%5.1f TF on the unpadded dims, frac %.3f)\n", names[v], us[v][3], us[v][0], fl / us[v][3] / 1e6,
            fl / us[v][3] / 1e6 / 157.3);
