@@ -194,3 +194,32 @@ int main() {
         assert res.returncode == 0, res.stderr
         run = subprocess.run([exe], capture_output=True, text=True)
         assert run.returncode == 0 and run.stdout.strip() == "ok", run.stdout + run.stderr
+
+
+def test_strips_kernel_loop_is_clean():
+    """k_wgrad_strips (csrc/wgrad2.h) uses the MFMA builtin: the K loop must hold no accumulator copies (the allocator has been seen
+    to rename accumulators inside such loops - 124 v_accvgpr_mov per three K-steps in the 16-wide experiment), no scratch, and only
+    a handful of VALU instructions (its staging addresses are buffer resources + scalar offsets)."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "k.hip")
+        with open(src, "w") as f:
+            f.write(f'#include "{CSRC}/wgrad2.h"\ntemplate __global__ void sdrm::k_wgrad_strips<11>(const sdrm::Wg2Args);\n')
+        out = os.path.join(d, "k.s")
+        res = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        asm = open(out).read()
+    ks = _kernels(asm)
+    (name,) = [n for n in ks if "k_wgrad_strips" in n]
+    ins = ks[name]
+    loops = _loops(ins)
+    inner = [(a, b) for a, b in loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in loops)]
+    kloops = [(a, b) for a, b in inner if sum(1 for x in ins[a:b] if x.startswith("v_mfma")) >= 88]
+    assert kloops
+    for a, b in kloops:
+        body = ins[a:b]
+        nm = sum(1 for x in body if x.startswith("v_mfma"))
+        assert sum(1 for x in body if x.startswith(("v_accvgpr_mov", "v_accvgpr_write"))) == 0
+        assert not [x for x in body if x.startswith("scratch_")]
+        valu = [x for x in body if x.startswith("v_") and not x.startswith(("v_mfma", "v_accvgpr_read"))]
+        assert len(valu) * 8 <= nm, (len(valu), nm, valu[:6])
