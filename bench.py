@@ -153,8 +153,49 @@ def cpu_baseline(wl, min_seconds=10.0, max_seconds=30.0):
 OTHER = {   # BASELINE.json configs besides the benched one (README hyper-parameters)
     "ML-100k/SVD  B=550 L=830 T=83 H=2 n=843": dict(L=830, W=830, T=83, H=2, B=550, n=843),
     "ML-1M/MLP    B=160 L=340 T=78 H=1 n=5429 (README batch)": dict(L=340, W=340, T=78, H=1, B=160, n=5429),
+    # the batch sweep of C3 (160, 512, 2048, 8192): train step only - the sampled rows are the same
+    "ML-1M/MLP    B=512 L=340 T=78 H=1 (batch sweep)": dict(L=340, W=340, T=78, H=1, B=512, n=0),
+    "ML-1M/MLP    B=2048 L=340 T=78 H=1 (batch sweep)": dict(L=340, W=340, T=78, H=1, B=2048, n=0),
     "ADM/NeuMF    B=850 L=40 T=93 H=5 n=9558": dict(L=40, W=40, T=93, H=5, B=850, n=9558),
 }
+
+
+def cpu_config_rates(c, seconds=2.0):
+    """The CPU oracle (torch CPU ops, all granted host cores) on one of the other configs: train steps for about `seconds`,
+    then full-resolution reverse steps for about `seconds` - the same-box CPU figure beside each GPU figure of
+    `other_configs` (BASELINE.json config 2 is literally "HIP denoiser vs CPU baseline")."""
+    from oracle import sdrm_oracle as orc
+    L, W, T, H, B, n = c["L"], c["W"], c["T"], c["H"], c["B"], c["n"]
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    o = orc.Oracle(L, W, T, H, synth.init_params(L, W, T, H, seed=1))
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0))
+    g = torch.Generator().manual_seed(0)
+
+    def train():
+        eps = torch.randn(B, L, generator=g)
+        t = torch.randint(1, T + 1, (B,), generator=g)
+        keeps = [(torch.rand(B, L, generator=g) < 0.5).float() for _ in range(3)]
+        o.train_step(x0, eps, t, keeps, 1e-5)
+
+    out = {"cores": cores}
+    train()   # warm-up
+    k, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds or k < 2:
+        train()
+        k += 1
+    out["train_steps_per_s"] = round(k / (time.perf_counter() - t0), 2)
+    if n > 0:
+        x = torch.randn(n, L, generator=g)
+        k, i, t0 = 0, T, time.perf_counter()
+        while time.perf_counter() - t0 < seconds or k < 2:
+            keep = (torch.rand(n, L, generator=g) < 0.5).float()
+            z = torch.randn(n, L, generator=g) if i > 1 else torch.zeros(n, L)
+            x = orc.reverse_update(x, o.forward(x, torch.full((n,), i, dtype=torch.int64), keep), z, i, o.beta, o.alpha, o.alphabar)
+            i = i - 1 if i > 1 else T
+            k += 1
+        out["sample_steps_per_s"] = round(k / (time.perf_counter() - t0), 2)
+    return out
 
 
 HBM_ACHIEVABLE_TBS = 6.3   # SURVEY.md section 8d: achievable HBM stream rate the byte roofline is priced against
@@ -168,10 +209,11 @@ def sample_bytes(n, L):           # PHILOX mode: x read + x write
     return 2.0 * n * L * 4
 
 
-def other_configs():
+def other_configs(with_cpu=True):
     """The other BASELINE.json configs (parity-test cases, not the headline): steps/s, kernel launches per step and the
     section-8d roofline time max(flops / 157.3 TF, bytes / 6.3 TB/s) beside the measured step time.  These are latency
-    bound (2-164 us of roofline time in 5-17 launches), so `frac` says how far the launch chain is from the arithmetic."""
+    bound (2-164 us of roofline time in 3-12 launches), so `frac` says how far the launch chain is from the arithmetic.
+    with_cpu: the CPU oracle on the same shapes and the same box beside each figure (`cpu_steps_per_s`, `cpu_cores`)."""
     from sdrm_amd.engine import Engine
     res = {}
     for name, c in OTHER.items():
@@ -180,7 +222,7 @@ def other_configs():
         eng.set_params(synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H))
         x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)).cuda()
         entry = {}
-        for kind in ("train", "sample_full", "sample_multires"):
+        for kind in (("train", "sample_full", "sample_multires") if n > 0 else ("train",)):
             if kind == "train":
                 fn, reps = (lambda: eng.train_step(x0, 1e-5, seed=1, step=3)), 100
                 roof_us = max(train_flops(B, L, T, H) / (PEAK_FP32_TFLOPS * 1e12), train_bytes(B, L, W, T, H) / (HBM_ACHIEVABLE_TBS * 1e12)) * 1e6
@@ -213,6 +255,15 @@ def other_configs():
                     pass
                 eng.sample_end()
         eng.close()
+        if with_cpu:
+            cpu = cpu_config_rates(c)
+            entry["train"]["cpu_steps_per_s"] = cpu["train_steps_per_s"]
+            entry["train"]["speedup_vs_cpu"] = round(entry["train"]["steps_per_s"] / cpu["train_steps_per_s"], 1)
+            if "sample_full" in entry:
+                entry["sample_full"]["cpu_steps_per_s"] = cpu["sample_steps_per_s"]
+                entry["sample_full"]["speedup_vs_cpu"] = round(entry["sample_full"]["steps_per_s"] / cpu["sample_steps_per_s"], 1)
+            entry["cpu_cores"] = cpu["cores"]
+            entry["cpu_kind"] = "port (oracle/sdrm_oracle.py on torch CPU ops, about 2 s per leg)"
         res[name] = entry
     return res
 
@@ -503,6 +554,15 @@ def main():
         rank_info = [None] * world
         dist.all_gather_object(rank_info, mine)
 
+    # the in-library exchange was agreed on: every rank's communicator must then span the whole job - a record that says
+    # "RCCL" while some rank ran alone is worse than no record
+    if use_abi and trainer is not None and isinstance(trainer, RcclTrainer):
+        bad = [r for r in rank_info if r is None or r.get("comm_nranks") != world]
+        if bad:
+            if rank == 0:
+                print(f"bench.py: the RCCL communicator does not span the job ({world} ranks): {bad}", file=sys.stderr)
+            sys.exit(4)
+
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else None
         roof = None
@@ -553,7 +613,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_other_configs:
-            out["other_configs"] = other_configs()
+            out["other_configs"] = other_configs(with_cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

@@ -70,7 +70,7 @@ typedef struct sdrm_train_randoms {
  * (train_SDRM.py:86-95, :305) able to process up to max_rows rows per call, with Adam state
  * (train_SDRM.py:309) and the DDPM schedule for beta1=1e-4, beta2=0.02 (train_SDRM.py:275-276,
  * 300-303).  Parameters start at zero: call sdrm_set_params.  Envelope: 1<=L,W<=4096, 2<=T<=1024,
- * 0<=H<=16. */
+ * 0<=H<=16 (the reference's search space, hyperparameter_search.py:103-113, is L=W<=1000, T<=198, H<=5). */
 int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_engine** out);
 int sdrm_destroy(sdrm_engine* e);
 const char* sdrm_last_error(const sdrm_engine* e);

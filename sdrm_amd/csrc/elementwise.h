@@ -15,7 +15,10 @@ namespace sdrm {
 constexpr int RC_USERS = 32;            // users per group
 constexpr int RC_ROWS = 3 * RC_USERS;   // stacked rows per group
 __host__ __device__ inline int rc_row(int pass, int user) { return RC_ROWS * (user / RC_USERS) + RC_USERS * pass + (user % RC_USERS); }
+// grouped: 0 BLOCKED, 1 GROUPED by 32 users (rowchain.h), 2 grouped by 16 users (the narrow nets' work-groups, skinny_step.h:
+// row = 48 * (user / 16) + 16 * pass + user % 16)
 __host__ __device__ inline size_t stacked_row(int grouped, int pass, int user, int B) {
+  if (grouped == 2) return (size_t)(48 * (user / 16) + 16 * pass + (user % 16));
   return grouped ? (size_t)rc_row(pass, user) : (size_t)pass * B + user;
 }
 
@@ -30,7 +33,7 @@ constexpr float MU2 = 0.01f;        // mu ** 2, :196
 // (all rows share t) also B0tab[t][w] = b0[w] + C0[t][w].
 struct EmbTabArgs {
   const float* temb; const float* We; const float* be; const float* W0; const float* b0;
-  float* Etab; float* W0c; float* B0tab;
+  float* W0c; float* B0tab;
   int L, W, T, LP, WP, K0;
   int ones_col;   // pad column of B0tab that holds 1.0 in every row (-1: none): the layer-0 pre-activation of that column is then 1
                   // in every stacked row, the "ones column" the strip-owned weight gradients take the bias gradients from (wgrad2.h)
@@ -112,7 +115,6 @@ __device__ __forceinline__ void emb_tables_row(const EmbTabArgs& a, int t, float
   for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
     const float s = a.be[j] + dot_unrolled(a.We + (size_t)j * a.T, tr, a.T);
     er[j] = s;
-    a.Etab[(size_t)t * a.T + j] = s;
   }
   __syncthreads();
   const int ldw = a.L + a.T;
@@ -134,7 +136,7 @@ __device__ __forceinline__ void emb_tables_row4(const EmbTabArgs& a, int t, floa
   const int q = threadIdx.x >> 2, l4 = threadIdx.x & 3, nq = blockDim.x >> 2;
   for (int j = q; j < a.T; j += nq) {
     const float s = a.be[j] + dot_quad<20>(a.We + (size_t)j * a.T, 1, tr, 1, a.T, l4);
-    if (l4 == 0) { er[j] = s; a.Etab[(size_t)t * a.T + j] = s; }
+    if (l4 == 0) er[j] = s;
   }
   __syncthreads();
   const int ldw = a.L + a.T;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(1024) void k_emb_tables(const EmbTabArgs a) {
   float touched = 0.f;
   for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < a.warm_lines; i += gridDim.x * blockDim.x) touched += a.warm[(size_t)i * 32];
   emb_tables_row4(a, blockIdx.x, sh);
-  if (touched == 1.2345678e-30f) a.Etab[0] = touched;   // (keeps the loads; never true in practice, harmless if it were: one table entry)
+  if (touched == 1.2345678e-30f) a.W0c[a.LP] = touched;   // (keeps the loads; never true in practice, harmless if it were: one table entry)
 }
 
 // four consecutive columns of an unpadded [rows, L] matrix (vector load when rows are 16-B aligned)
@@ -172,11 +174,13 @@ __device__ __forceinline__ float4 load4_unpadded(const float* __restrict__ x, in
 //   U[0*B + r] = 2*keep1 * (sqrt(abar[t]) x0 + (1-abar[t]) eps)      pass P (:328,:331)
 //   U[1*B + r] = 2*keep2 * x0                                         pass S (:193)
 //   U[2*B + r] = 2*keep3 * (x0 + 0.1 eps)                             pass Q (:194-195)
-// columns [L,LP) zero, columns LP + t = 1 (one-hot, multiplies the per-step table C0^T stored in the
-// trailing columns of W0c).  Rows [3B, MP) are zero-filled.
+// columns [L,LP) zero, columns LP + i = temb[t][i] (the row's sinusoidal time embedding, train_SDRM.py:105-112: the layer-0
+// weight gradient then delivers M = dpre0^T * temb beside d dnn.0.weight[:, :L], and every gradient of the embedding path
+// is a product of M with the parameters - tail.h).  Rows [3B, MP) are zero-filled.
 struct PrepTrainArgs {
   const float* x0; const float* noise; const int64_t* t; const uint8_t* keep;
   const float* sqrt_ab; const float* one_minus_ab;
+  const float* tembP;   // [T+1][K0 - LP]: the time-embedding table, rows padded with zeros
   float* U; int* tdev;
   int B, L, LP, K0, T, MP;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
@@ -268,9 +272,9 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
       }
     }
   } else {
-    const int h = c - a.LP;  // one-hot region
-#pragma unroll
-    for (int j = 0; j < 4; ++j) vP[j] = vS[j] = vQ[j] = ((h + j) == tt) ? 1.f : 0.f;
+    const int h = c - a.LP;  // the row's time embedding (the three passes share t)
+    const float4 te = *reinterpret_cast<const float4*>(a.tembP + (size_t)tt * (a.K0 - a.LP) + h);
+    vP[0] = vS[0] = vQ[0] = te.x; vP[1] = vS[1] = vQ[1] = te.y; vP[2] = vS[2] = vQ[2] = te.z; vP[3] = vS[3] = vQ[3] = te.w;
   }
   *reinterpret_cast<float4*>(a.U + (size_t)r * a.K0 + c) = make_float4(vP[0], vP[1], vP[2], vP[3]);
   *reinterpret_cast<float4*>(a.U + (size_t)(a.B + r) * a.K0 + c) = make_float4(vS[0], vS[1], vS[2], vS[3]);
@@ -479,104 +483,13 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Embedding-path backward.  k_grad_finalize first reduces the one-hot columns of the layer-0 weight
-// gradient slabs into a dense dC0T[w][t] = sum over rows with timestep t of dpre0[row][w]  ([W][TP]).
-//   k_emb_bwd1:  dE[t][j]   = sum_w dC0T[w][t] * W0[w][L+j]   and (independent, extra blocks)
-//                dW0[w][L+j] = sum_t dC0T[w][t] * E[t][j]
-//   k_emb_bwd2:  dWe[j][i]  = sum_t dE[t][j] * temb[t][i] ;  dbe[j] = sum_t dE[t][j]
-struct EmbBwdArgs {
-  const float* dC0T; int TP;
-  const float* W0; const float* Etab; const float* temb;
-  float* dE; float* g; int64_t off_we, off_be, off_w0;
-  int L, W, T;
-};
-
-// Blocks [0, T]: dE row t (1024 threads = 16 w-slices x 64 j-lanes, every lane carries columns j and j + 64 at once; the
-// slices meet in LDS).  Blocks beyond: the independent product dW0[:, L:] = dC0^T * E, 256 outputs per block, four
-// lanes per output.  These kernels are latency chains: what counts is the number of dependent memory round trips.
-__global__ __launch_bounds__(1024) void k_emb_bwd1(const EmbBwdArgs a) {
-  __shared__ float red[16][128];
-  if ((int)blockIdx.x > a.T) {
-    const int i = ((int)blockIdx.x - a.T - 1) * 256 + (threadIdx.x >> 2);
-    if (i < a.W * a.T) {   // quad-uniform
-      const int w = i / a.T, j = i - w * a.T;
-      const float s = dot_quad<20>(a.dC0T + (size_t)w * a.TP, 1, a.Etab + j, a.T, a.T + 1, threadIdx.x & 3);
-      if ((threadIdx.x & 3) == 0) a.g[a.off_w0 + (int64_t)w * (a.L + a.T) + a.L + j] = s;
-    }
-    return;
-  }
-  const int t = blockIdx.x;
-  const int jj = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int ldw = a.L + a.T;
-  const int wlo = (a.W * part) / 16, whi = (a.W * (part + 1)) / 16;
-  for (int j0 = 0; j0 < a.T; j0 += 128) {
-    const int j = j0 + jj, j2 = j + 64;
-    const bool in1 = j < a.T, in2 = j2 < a.T;
-    float s1 = 0.f, s2 = 0.f;
-    constexpr int NB = 16;   // 48 loads in flight (a 1024-thread block has 128 VGPRs per lane)
-    for (int w0 = wlo; w0 < whi; w0 += NB) {
-      float dv[NB], y1[NB], y2[NB];
-#pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int w = w0 + u;
-        const bool in = w < whi;
-        const unsigned od = (unsigned)w * (unsigned)a.TP + (unsigned)t;          // 32-bit offsets from uniform bases:
-        const unsigned ow = (unsigned)w * (unsigned)ldw + (unsigned)(a.L + j);   // half the address registers
-        dv[u] = in ? a.dC0T[od] : 0.f;
-        y1[u] = (in && in1) ? a.W0[ow] : 0.f;
-        y2[u] = (in && in2) ? a.W0[ow + 64u] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < NB; ++u) { s1 = fmaf(dv[u], y1[u], s1); s2 = fmaf(dv[u], y2[u], s2); }
-    }
-    __syncthreads();
-    red[part][jj] = s1;
-    red[part][jj + 64] = s2;
-    __syncthreads();
-    if (threadIdx.x < 128 && j0 + (int)threadIdx.x < a.T) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) s += red[q][threadIdx.x];
-      a.dE[(size_t)t * a.T + j0 + threadIdx.x] = s;
-    }
-  }
-}
-
-// four lanes per output: dWe (T*T outputs), then dbe (T outputs)
-__global__ __launch_bounds__(256) void k_emb_bwd2(const EmbBwdArgs a) {
-  const int n2 = a.T * a.T, n3 = a.T;
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, l4 = threadIdx.x & 3;
-  const int nt = a.T + 1;
-  if (i < n2) {
-    const int j = i / a.T, ii = i - j * a.T;
-    const float s = dot_quad<20>(a.dE + j, a.T, a.temb + ii, a.T, nt, l4);
-    if (l4 == 0) a.g[a.off_we + i] = s;
-  } else if (i < n2 + n3) {
-    const int j = i - n2;
-    float s = 0.f;
-    for (int t0 = l4; t0 < nt; t0 += 4 * 20) {
-      float v[20];
-#pragma unroll
-      for (int u = 0; u < 20; ++u) v[u] = (t0 + 4 * u < nt) ? a.dE[(size_t)(t0 + 4 * u) * a.T + j] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 20; ++u) s += v[u];
-    }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (l4 == 0) a.g[a.off_be + j] = s;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Slab reduction into the flat gradient, and Adam + re-pack of the padded compute copies.
+// Adam on a given flat gradient + re-pack of the padded compute copies (sdrm_adam_step, sdrm_set_params; the single-GPU step
+// applies Adam straight from the weight-gradient slabs: tail.h).
 struct Job {
   int64_t flat_off;   // offset of the tensor in the flat vectors
   int rows, cols;     // logical shape; flat row stride = flat_ld
   int flat_ld;
-  int ncols;          // columns [0,ncols) of each row are covered by this job (dnn.0.weight: L of L+T)
-  const float* src; int src_ld; size_t slab_stride; int nslabs;   // finalize source (padded slabs)
-  int inner;          // >1: scalar job, sum src[k*slab_stride + q] over k<nslabs, q<inner (slope partials)
-  float* gdst; int g_ld;   // where k_grad_finalize writes: flat gradient (g + flat_off, flat_ld) or a scratch table
+  int ncols;          // columns [0,ncols) of each row have a compute copy (dnn.0.weight: L of L+T)
   float* dst; int dst_ld;                                          // compute copy (may be null)
   float* dstT; int dstT_ld;                                        // transposed compute copy [col][row] (may be null)
   float* dstF; float* dstFT; int fnct;                             // fragment-packed copies of the matrix / of its transpose for the
@@ -602,72 +515,7 @@ __host__ __device__ inline int rc_light_klast(int K, int KP) {
   return (KP >= 32 && r >= 1 && r <= 4) ? KP / 16 - 1 : -1;
 }
 constexpr int MAX_JOBS = 12;
-struct JobTable { Job j[MAX_JOBS]; int n; int n_adam; };
-
-// Four lanes share one group of 4 consecutive padded columns: each sums a quarter of the slabs with
-// 16-byte loads (eight in flight: one round trip for up to 32 slabs), then the quarters meet through the wave.  Keeps ~8 MB of loads in flight
-// chip-wide, which is what an HBM-bound reduction of S slabs needs.
-__global__ __launch_bounds__(256) void k_grad_finalize(const JobTable tab) {
-  const Job& jb = tab.j[blockIdx.y];
-  if (jb.src == nullptr) return;
-  if (jb.inner > 1) {   // scalar job (slope partials): one work-group, fixed order
-    if (blockIdx.x != 0) return;
-    // thousands of partials (one per dgrad work-group): every thread takes a batch of 16 with all loads in flight at
-    // once - a thread-serial loop here was a chain of dependent round trips longer than the rest of the kernel
-    __shared__ float red[4];
-    float a = 0.f;
-    const int total = jb.nslabs * jb.inner;
-    for (int i0 = 0; i0 < total; i0 += 256 * 16) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int i = i0 + u * 256 + (int)threadIdx.x;
-        v[u] = i < total ? jb.src[(size_t)(i / jb.inner) * jb.slab_stride + (i % jb.inner)] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) a += v[u];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) jb.gdst[0] = (red[0] + red[1]) + (red[2] + red[3]);
-    return;
-  }
-  const int qpr = (jb.ncols + 3) >> 2;                      // column quads per row
-  const int64_t total = (int64_t)jb.rows * qpr * 4;         // x4 slab quarters
-  const int part = threadIdx.x & 3;
-  const int kb = (jb.nslabs * part) >> 2, ke = (jb.nslabs * (part + 1)) >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t quad = i >> 2;
-    const int r = (int)(quad / qpr), c = 4 * (int)(quad - (int64_t)r * qpr);
-    const float* s = jb.src + (size_t)r * jb.src_ld + c;
-    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-    for (int k = kb; k < ke; k += 8) {   // eight slabs per batch, every load of the batch in flight at once
-      float4 vv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        vv[u] = (k + u < ke) ? *reinterpret_cast<const float4*>(s + (size_t)(k + u) * jb.slab_stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        a0.x += vv[u].x; a0.y += vv[u].y; a0.z += vv[u].z; a0.w += vv[u].w;
-        a1.x += vv[u + 1].x; a1.y += vv[u + 1].y; a1.z += vv[u + 1].z; a1.w += vv[u + 1].w;
-      }
-    }
-    float v[4] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] += __shfl_xor(v[j], 1, 64);
-      v[j] += __shfl_xor(v[j], 2, 64);
-    }
-    if (part == 0) {
-      float* d = jb.gdst + (int64_t)r * jb.g_ld + c;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c + j < jb.ncols) d[j] = v[j];
-    }
-  }
-}
+struct JobTable { Job j[MAX_JOBS]; int n; };
 
 // torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-4), coupled L2 (:309, Q8):
 //   g += wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -677,15 +525,27 @@ struct AdamArgs {
   int update;   // 0: only re-pack compute copies from p (set_params)
 };
 
+// One element's update, written once for every kernel that applies Adam (k_adam here, k_tail / k_tail_emb in tail.h), with
+// contraction off and the one fused multiply-add spelled out: the single-GPU step (Adam straight from the slab sums) and the
+// three-phase step (the same sums through the flat gradient, then k_adam) must leave the same bits in p, m and v whatever the
+// compiler would fuse in either context (tests/test_rccl_exchange.py).
+__device__ __forceinline__ float adam_math(float w, float g, float& m, float& v, float step_size, float bc2_sqrt, float b1, float b2,
+                                           float eps, float wd) {
+#pragma clang fp contract(off)
+  const float gg = fmaf(wd, w, g);
+  const float mm = b1 * m + (1.f - b1) * gg;
+  const float vv = b2 * v + ((1.f - b2) * gg) * gg;
+  m = mm; v = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  return w - step_size * (mm / denom);
+}
+
 __device__ __forceinline__ float adam_element(const AdamArgs& a, int64_t fi) {
   float w = a.p[fi];
   if (a.update) {
-    const float gg = a.g[fi] + a.wd * w;
-    const float mm = a.b1 * a.m[fi] + (1.f - a.b1) * gg;
-    const float vv = a.b2 * a.v[fi] + (1.f - a.b2) * gg * gg;
+    float mm = a.m[fi], vv = a.v[fi];
+    w = adam_math(w, a.g[fi], mm, vv, a.step_size, a.bc2_sqrt, a.b1, a.b2, a.eps, a.wd);
     a.m[fi] = mm; a.v[fi] = vv;
-    const float denom = sqrtf(vv) / a.bc2_sqrt + a.eps;
-    w = w - a.step_size * (mm / denom);
     a.p[fi] = w;
   }
   return w;

@@ -55,6 +55,7 @@ struct RowChainArgs {
   // step inputs (EXPLICIT mode: noise [B,L], t [B], keep [3,B,L]; PHILOX mode: null)
   const float* x0; const float* noise; const int64_t* t; const uint8_t* keep;
   const float* sqrt_ab; const float* one_minus_ab;
+  const float* tembP;   // [T+1][K0 - LPs]: the time-embedding table, rows padded with zeros
   int B, L, T, H;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
   // net: fragment-packed weights (layer 0: the latent columns only), biases, per-timestep bias table of layer 0
@@ -313,15 +314,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
   }
   __syncthreads();
   {
-    // one-hot(t) columns of U (read by the layer-0 weight gradient only; rows of users beyond the batch stay all-zero): the P, S
-    // and Q row of this thread's user, column quads sq + 8 j - issued first, they drain while the randoms are drawn
-    const int TQ8 = (a.K0 - a.LPs) >> 5;   // groups of eight quads (the one-hot block is a multiple of 32 columns wide)
-    const int tt = (susr < a.B) ? trow[su] : -1;
+    // the time-embedding columns of U, temb[t] of the row's timestep (read by the layer-0 weight gradient only: they deliver
+    // M = dpre0^T * temb, tail.h; rows of users beyond the batch stay all-zero): the P, S and Q row of this thread's user, column
+    // quads sq + 8 j - issued first, they drain while the randoms are drawn
+    const int TPc = a.K0 - a.LPs;          // a multiple of 32 columns
+    const int TQ8 = TPc >> 5;              // groups of eight quads
+    const bool uin = susr < a.B;
+    const float* trow_p = a.tembP + (size_t)(uin ? trow[su] : 0) * TPc + 4 * sq;
     const brsrc ures = make_brsrc(a.U + grow0 * a.K0, (uint32_t)(RC_ROWS * a.K0 * 4));
     const uint32_t uvo = (uint32_t)((su * a.K0 + a.LPs + 4 * sq) * 4);
     for (int jq = 0; jq < TQ8; ++jq) {
-      const int h = 4 * (sq + 8 * jq);
-      const f32x4 oh = {h == tt ? 1.f : 0.f, h + 1 == tt ? 1.f : 0.f, h + 2 == tt ? 1.f : 0.f, h + 3 == tt ? 1.f : 0.f};
+      const float4 te = uin ? *reinterpret_cast<const float4*>(trow_p + 32 * jq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const f32x4 oh = {te.x, te.y, te.z, te.w};
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) bstore4<true>(ures, uvo, (uint32_t)((pass * RC_USERS * a.K0 + 32 * jq) * 4), oh);
     }

@@ -21,7 +21,8 @@
 #include "rowchain.h"
 #include "select.h"
 #include "skinny.h"
-#include "skinny_train.h"
+#include "skinny_step.h"
+#include "tail.h"
 #include "dgrad_rows.h"
 #include "wgrad2.h"
 
@@ -78,6 +79,8 @@ struct sdrm_engine {
   float *W0f = nullptr, *Whf = nullptr, *Wof = nullptr;   // fragment-packed copies [WP/16][WP/16][64][4] for the row-owned forward
                                                           // (layer 0: the latent columns only); null when the net does not qualify
   bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
+  bool cur_sk = false;               // ... grouped by 16 users (the narrow nets' step, csrc/skinny_step.h)
+  bool tables_fresh = false;         // B0tab / the C0^T columns of W0c belong to the current parameters
   float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
                                      // the weight gradients of that step read their operand without PReLU on load
   bool cur_act = false;              // the last train_forward stored them
@@ -85,7 +88,8 @@ struct sdrm_engine {
                                      // the row-owned forward's staging into U): column ones_col of a weight-gradient slab is then the
                                      // bias gradient (csrc/wgrad2.h); -1: none
   bool bwd_strips = false;           // this backward's weight gradients: the strip-owned launch (bias gradients in slab column ones_col)
-  float *temb = nullptr, *Etab = nullptr, *B0tab = nullptr;
+  float *temb = nullptr, *tembP = nullptr, *B0tab = nullptr;   // time-embedding table [T+1][T]; the same with rows padded to TP (the
+                                                               // trailing columns of the train step's layer-0 operand); b0 + C0[t]
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
   float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *X = nullptr;
@@ -93,7 +97,7 @@ struct sdrm_engine {
   float *alpha_part = nullptr;
   int alpha_part_stride = 0;
   double *loss_part = nullptr, *sums = nullptr;
-  float *dC0 = nullptr, *dE = nullptr;
+  float *Mred = nullptr, *snap = nullptr;   // the tail's hand-over to its second launch (csrc/tail.h): M [W][TP]; We | be | W0e before the update
   int *tdev = nullptr;
   int64_t *Tj_dev = nullptr;
   int *rowid_dev = nullptr;
@@ -113,6 +117,7 @@ struct sdrm_engine {
   bool bwd_begun = false;
   bool fold_sums = false;            // sdrm_train_step: the seed kernel folds the loss partials itself (no k_loss_sums launch)
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
+  int bwd_hidden_apps = 0;           // slab sets of the shared hidden layer's weight gradient per K-slice: H (one per application), or 1 (already summed)
   int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
   // grow-only scratch of sdrm_vae_decode (padded latents / weights / hidden activations; the raw matrix when the caller keeps none)
   float* dec_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -427,69 +432,62 @@ int wgrad_tiles(const Tuning& tn, int Nout, int Kin) {
   return ((Nout + kCfgBM[c] - 1) / kCfgBM[c]) * ((Kin + kCfgBN[c] - 1) / kCfgBN[c]);
 }
 
-// bias_col >= 0: the weight gradients were the strip-owned launch (wgrad2.h) - the bias gradient of a layer is column bias_col of
-// its weight-gradient slabs (a strided [out] x 1 job) instead of the column-sum slabs of the 64x64-tile kernel
-void build_jobs(sdrm_engine* e, JobTable& tab, int S0, int SH, int SO, int dgrad_blocks, float* gdst = nullptr, int bias_col = -1) {
-  float* gbase = gdst ? gdst : e->g;
+// the parameter tensors and their compute copies, as k_adam (sdrm_adam_step, sdrm_set_params) walks them
+void build_jobs(sdrm_engine* e, JobTable& tab) {
   const int L = e->L, W = e->W, T = e->T, H = e->H;
   int n = 0;
-  auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, const float* src, int src_ld,
-                 size_t slab_stride, int nslabs, float* dst, int dst_ld, int inner = 1, float* dstT = nullptr,
-                 int dstT_ld = 0) {
+  auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, float* dst, int dst_ld, float* dstT = nullptr, int dstT_ld = 0) -> Job& {
     Job& j = tab.j[n++];
     j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
-    j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.dst = dst; j.dst_ld = dst_ld;
-    j.inner = inner;
-    j.dstT = dstT; j.dstT_ld = dstT_ld;
+    j.dst = dst; j.dst_ld = dst_ld; j.dstT = dstT; j.dstT_ld = dstT_ld;
     j.dstF = nullptr; j.dstFT = nullptr; j.fnct = e->WP / 16; j.fklast = -1; j.fklastT = -1;
-    j.gdst = gbase + off; j.g_ld = flat_ld;
+    return j;
   };
-  // emb_layer.weight + emb_layer.bias (gradient written by k_emb_bwd2; no compute copy)
-  add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0, 0, 0, nullptr, 0);
-  add(e->off_w0, W, L + T, L + T, L, e->slab0, e->K0, (size_t)e->WP * e->K0, S0, e->W0c, e->K0);
-  tab.j[n - 1].dstF = e->W0f; tab.j[n - 1].fklast = rc_light_klast(L, e->LP);
-  if (bias_col >= 0) add(e->off_b0, W, 1, 1, 1, e->slab0 + bias_col, e->K0, (size_t)e->WP * e->K0, S0, e->b0c, 1);
-  else add(e->off_b0, 1, W, W, W, e->db0s, 0, (size_t)e->WP, S0, e->b0c, 0);
-  // PReLU slopes: per-block partials of the dgrad epilogues, [application][alpha_part_stride]
-  add(e->off_a0, 1, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, nullptr, 0, dgrad_blocks);
-  if (H >= 1) {
-    add(e->off_wh, W, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, H * SH, e->Whc, e->WP, 1, e->WhcT, e->WP);
-    tab.j[n - 1].dstF = e->Whf; tab.j[n - 1].dstFT = e->WhfT; tab.j[n - 1].fklast = tab.j[n - 1].fklastT = rc_light_klast(W, e->WP);
-    if (bias_col >= 0) add(e->off_bh, W, 1, 1, 1, e->slabH + bias_col, e->WP, (size_t)e->WP * e->WP, H * SH, e->bhc, 1);
-    else add(e->off_bh, 1, W, W, W, e->dbHs, 0, (size_t)e->WP, H * SH, e->bhc, 0);
-    add(e->off_ah, 1, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, nullptr, 0,
-        dgrad_blocks);
+  add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0);   // emb_layer.weight + emb_layer.bias (no compute copy)
+  {
+    Job& j = add(e->off_w0, W, L + T, L + T, L, e->W0c, e->K0);
+    j.dstF = e->W0f; j.fklast = rc_light_klast(L, e->LP);
   }
-  add(e->off_wo, L, W, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO, e->Woc, e->WP, 1, e->WocT, e->LP);
-  tab.j[n - 1].dstF = e->Wof; tab.j[n - 1].dstFT = e->WofT; tab.j[n - 1].fklast = rc_light_klast(W, e->WP); tab.j[n - 1].fklastT = rc_light_klast(L, e->LP);
-  if (bias_col >= 0) add(e->off_bo, L, 1, 1, 1, e->slabO + bias_col, e->WP, (size_t)e->LP * e->WP, SO, e->boc, 1);
-  else add(e->off_bo, 1, L, L, L, e->dbOs, 0, (size_t)e->LP, SO, e->boc, 0);
-  tab.n_adam = n;
-  // finalize-only job: the one-hot columns of the layer-0 slabs -> dense dC0T[W][TP] for the emb backward
-  add(0, W, 0, 0, T + 1, e->slab0 + e->LP, e->K0, (size_t)e->WP * e->K0, S0, nullptr, 0);
-  tab.j[n - 1].gdst = e->dC0; tab.j[n - 1].g_ld = e->TP;
+  add(e->off_b0, 1, W, W, W, e->b0c, 0);
+  add(e->off_a0, 1, 1, 1, 1, nullptr, 0);
+  if (H >= 1) {
+    Job& j = add(e->off_wh, W, W, W, W, e->Whc, e->WP, e->WhcT, e->WP);
+    j.dstF = e->Whf; j.dstFT = e->WhfT; j.fklast = j.fklastT = rc_light_klast(W, e->WP);
+    add(e->off_bh, 1, W, W, W, e->bhc, 0);
+    add(e->off_ah, 1, 1, 1, 1, nullptr, 0);
+  }
+  {
+    Job& j = add(e->off_wo, L, W, W, W, e->Woc, e->WP, e->WocT, e->LP);
+    j.dstF = e->Wof; j.dstFT = e->WofT; j.fklast = rc_light_klast(W, e->WP); j.fklastT = rc_light_klast(L, e->LP);
+  }
+  add(e->off_bo, 1, L, L, L, e->boc, 0);
   tab.n = n;
+}
+
+// Adam's bias corrections of step e->adam_t (train_SDRM.py:337; torch.optim.Adam: step_size = lr / (1 - b1^k), denominators
+// scaled by sqrt(1 - b2^k))
+void adam_scalars(const sdrm_engine* e, float lr, float& step_size, float& bc2_sqrt) {
+  const double k = (double)e->adam_t;
+  const double bc1 = 1.0 - std::pow(0.9, k), bc2 = 1.0 - std::pow(0.999, k);
+  step_size = (float)((double)lr / bc1);
+  bc2_sqrt = (float)std::sqrt(bc2);
 }
 
 int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStream_t st) {
   JobTable tab;
-  build_jobs(e, tab, 1, 1, 1, 1);
+  build_jobs(e, tab);
   AdamArgs a{};
   a.p = e->p; a.m = e->m; a.v = e->v; a.g = grad ? grad : e->g;
   a.b1 = 0.9f; a.b2 = 0.999f; a.eps = 1e-8f; a.wd = 1e-4f; a.update = update;
-  if (update) {
-    const double k = (double)e->adam_t;
-    const double bc1 = 1.0 - std::pow(0.9, k), bc2 = 1.0 - std::pow(0.999, k);
-    a.step_size = (float)((double)lr / bc1);
-    a.bc2_sqrt = (float)std::sqrt(bc2);
-  }
+  if (update) adam_scalars(e, lr, a.step_size, a.bc2_sqrt);
   // enough work-groups that the largest tensor is one or two passes per thread (a pass is a chain of dependent loads)
   int64_t biggest = 0;
-  for (int k = 0; k < tab.n_adam; ++k) biggest = std::max<int64_t>(biggest, (int64_t)tab.j[k].rows * tab.j[k].cols);
+  for (int k = 0; k < tab.n; ++k) biggest = std::max<int64_t>(biggest, (int64_t)tab.j[k].rows * tab.j[k].cols);
   const int gx = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (biggest + 511) / 512));
-  dim3 grid(gx, tab.n_adam);
+  dim3 grid(gx, tab.n);
   SDRM_LAUNCH(e, k_adam, grid, dim3(256), 0, st, tab, a);
   HIP_TRY(e, hipGetLastError());
+  e->tables_fresh = false;
   return SDRM_OK;
 }
 
@@ -552,22 +550,28 @@ int launch_wgrad_strips(sdrm_engine* e, int MP, double flops, hipStream_t st) {
   }
 }
 
-EmbTabArgs emb_args(sdrm_engine* e, bool for_sampling) {
+EmbTabArgs emb_args(sdrm_engine* e) {
   EmbTabArgs a{};
   a.temb = e->temb; a.We = e->p + e->off_we; a.be = e->p + e->off_be; a.W0 = e->p + e->off_w0; a.b0 = e->p + e->off_b0;
-  a.Etab = e->Etab; a.W0c = e->W0c; a.B0tab = for_sampling ? e->B0tab : nullptr;
+  a.W0c = e->W0c; a.B0tab = e->B0tab;
   a.L = e->L; a.W = e->W; a.T = e->T; a.LP = e->LP; a.WP = e->WP; a.K0 = e->K0;
   a.ones_col = e->ones_col;
   return a;
 }
 
-int emb_tables(sdrm_engine* e, bool for_sampling, hipStream_t st, const float* warm = nullptr, size_t warm_floats = 0) {
-  EmbTabArgs a = emb_args(e, for_sampling);
+// The time-embedding tables of the current parameters: B0tab[t] = b0 + C0[t] (what layer 0 of a train step or of a sampling step
+// adds per row) and C0^T in the trailing columns of W0c (what the plain forward multiplies its one-hot(t) columns with).
+int emb_tables(sdrm_engine* e, hipStream_t st, const float* warm = nullptr, size_t warm_floats = 0) {
+  EmbTabArgs a = emb_args(e);
   a.warm = warm; a.warm_lines = warm ? (unsigned)std::min<size_t>(warm_floats / 32, 1u << 24) : 0u;
   SDRM_LAUNCH(e, k_emb_tables, dim3(e->T + 1), dim3(1024), 2 * e->T * sizeof(float), st, a);
   HIP_TRY(e, hipGetLastError());
+  e->tables_fresh = true;
   return SDRM_OK;
 }
+// ... made only when the parameters changed since they were last made (sdrm_set_params, sdrm_adam_step, a train step whose tail
+// did not make them itself: csrc/tail.h, k_tail_emb_tab)
+int ensure_tables(sdrm_engine* e, hipStream_t st) { return e->tables_fresh ? SDRM_OK : emb_tables(e, st); }
 
 bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && e->WP <= 64; }
 
@@ -687,7 +691,7 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   RowChainArgs a{};
   a.x0 = x0;
   if (mode == SDRM_RNG_EXPLICIT) { a.noise = rnd->noise; a.t = rnd->t; a.keep = rnd->keep; }
-  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n;
+  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n; a.tembP = e->tembP;
   a.B = B; a.L = e->L; a.T = e->T; a.H = e->H;
   a.mode = mode; a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.step = (uint32_t)step; a.row0 = row0; a.nd = nd;
   a.W0f = e->W0f; a.Whf = e->Whf; a.Wof = e->Wof; a.bh = e->bhc; a.bo = e->boc; a.B0tab = e->B0tab; a.ldtab = e->WP;
@@ -710,46 +714,53 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   }
 }
 
-SkinnyTrainArgs skinny_train_args(sdrm_engine* e, int B, int MP) {
-  SkinnyTrainArgs a{};
+// the narrow nets' train step (csrc/skinny_step.h): forward (which = 0) / backward (which = 1) over G = ceil(B / 16) user groups
+SkStepArgs sk_step_args(sdrm_engine* e, int B) {
+  SkStepArgs a{};
   const int n = e->T + 1;
   a.W0c = e->W0c; a.K0 = e->K0; a.Whc = e->Whc; a.Woc = e->Woc; a.bh = e->bhc; a.bo = e->boc;
   a.WhcT = e->WhcT; a.WocT = e->WocT; a.B0tab = e->B0tab;
   a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
-  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n;
-  a.B = B; a.L = e->L; a.W = e->W; a.T = e->T; a.H = e->H; a.MP = MP; a.LPs = e->LP; a.WPs = e->WP;
+  a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n; a.tembP = e->tembP;
+  a.B = B; a.L = e->L; a.W = e->W; a.T = e->T; a.H = e->H; a.G = (B + SK_USERS - 1) / SK_USERS;
+  a.LPs = e->LP; a.WPs = e->WP; a.TPs = e->TP;
   a.U = e->U; a.tdev = e->tdev; a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.Y = e->Y;
-  a.dY = e->dY; a.dpre = e->dA; a.alpha_part = e->alpha_part; a.alpha_part_stride = e->alpha_part_stride;
+  a.loss_part = e->loss_part;
+  a.slab0 = e->slab0; a.slabH = e->slabH; a.slabO = e->slabO; a.db0s = e->db0s; a.dbHs = e->dbHs; a.dbOs = e->dbOs;
+  a.alpha_part = e->alpha_part; a.alpha_part_stride = e->alpha_part_stride;
   return a;
 }
 
-// one of the two fused skinny train kernels (fwd: which = 0, dgrad chain: which = 1) on MP stacked rows:
-// one work-group per 16 rows, one wave per 16-column tile
-int launch_skinny_train(sdrm_engine* e, const SkinnyTrainArgs& ka, int which, hipStream_t st) {
-  const int NL = (e->L + 15) / 16, NW = (e->W + 15) / 16;   // tiles with real columns (1..4 each)
-  dim3 grid(ka.MP / 16), block(64 * (NL > NW ? NL : NW));
-#define SKT_LAUNCH(nl, nw)                                                                         \
-  do {                                                                                             \
-    if (which == 0) SDRM_LAUNCH(e, (k_skinny_train_fwd<nl, nw>), grid, block, 0, st, ka);      \
-    else SDRM_LAUNCH(e, (k_skinny_train_bwd<nl, nw>), grid, block, 0, st, ka);                 \
-  } while (0)
-#define SKT_ROW(nl)                                 \
-  switch (NW) {                                     \
-    case 1: SKT_LAUNCH(nl, 1); break;               \
-    case 2: SKT_LAUNCH(nl, 2); break;               \
-    case 3: SKT_LAUNCH(nl, 3); break;               \
-    default: SKT_LAUNCH(nl, 4); break;              \
+template <int NL, int NW>
+int launch_sk_step_nlnw(sdrm_engine* e, const SkStepArgs& ka, int which, int grid, hipStream_t st) {
+  typedef SkCfg<NL, NW> C;
+  const size_t lds = (which == 0 ? sk_fwd_lds_floats<NL, NW>() : sk_bwd_lds_floats<NL, NW>(ka.TPs)) * sizeof(float);
+  if (lds > 48 * 1024) {
+    if (which == 0) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_bwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  switch (NL) {
-    case 1: SKT_ROW(1); break;
-    case 2: SKT_ROW(2); break;
-    case 3: SKT_ROW(3); break;
-    default: SKT_ROW(4); break;
-  }
-#undef SKT_ROW
-#undef SKT_LAUNCH
+  if (which == 0) SDRM_LAUNCH(e, (k_skinny_fwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
+  else SDRM_LAUNCH(e, (k_skinny_bwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
+}
+
+int launch_sk_step(sdrm_engine* e, const SkStepArgs& ka, int which, int grid, hipStream_t st) {
+  const int NL = (e->L + 15) / 16, NW = (e->W + 15) / 16;   // tiles with real columns (1..4 each)
+#define SK_ROW(nl)                                                                  \
+  switch (NW) {                                                                     \
+    case 1: return launch_sk_step_nlnw<nl, 1>(e, ka, which, grid, st);              \
+    case 2: return launch_sk_step_nlnw<nl, 2>(e, ka, which, grid, st);              \
+    case 3: return launch_sk_step_nlnw<nl, 3>(e, ka, which, grid, st);              \
+    default: return launch_sk_step_nlnw<nl, 4>(e, ka, which, grid, st);             \
+  }
+  switch (NL) {
+    case 1: SK_ROW(1)
+    case 2: SK_ROW(2)
+    case 3: SK_ROW(3)
+    default: SK_ROW(4)
+  }
+#undef SK_ROW
 }
 
 // eps-net layers 1..H and the output pre-activation inputs; layer 0 is launched by the caller
@@ -851,6 +862,8 @@ int upload_temb(sdrm_engine* e) {
       tab[(size_t)t * T + half + k] = std::sin(arg);
     }
   HIP_TRY(e, hipMemcpy(e->temb, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  // rows padded to TP floats: what the train step's staging copies into the trailing columns of the layer-0 operand
+  HIP_TRY(e, hipMemcpy2D(e->tembP, (size_t)e->TP * 4, tab.data(), (size_t)T * 4, (size_t)T * 4, (size_t)(T + 1), hipMemcpyHostToDevice));
   return SDRM_OK;
 }
 
@@ -1009,7 +1022,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     HIP_TRY(e, dalloc(&e->act, (size_t)(H + 1) * e->MPmax * e->WP));
     if (round_up(W, 4) < e->WP) e->ones_col = round_up(W, 4);
   }
-  HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->Etab, (size_t)n * T));
+  HIP_TRY(e, dalloc(&e->temb, (size_t)n * T)); HIP_TRY(e, dalloc(&e->tembP, (size_t)n * e->TP));
   HIP_TRY(e, dalloc(&e->B0tab, (size_t)n * e->WP)); HIP_TRY(e, dalloc(&e->sched, (size_t)8 * n));
   HIP_TRY(e, dalloc(&e->rev_dev, (size_t)3 * n));
   {
@@ -1041,8 +1054,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   }
   e->alpha_part_stride = std::max(max_gemm_blocks((int)MP, e->WP), (int)MP / 16);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
-  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, MP / RC_ROWS + 1))); HIP_TRY(e, dalloc(&e->sums, 8));
-  HIP_TRY(e, dalloc(&e->dC0, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->dE, (size_t)n * T));
+  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, MP / SK_ROWS + 1))); HIP_TRY(e, dalloc(&e->sums, 8));
+  HIP_TRY(e, dalloc(&e->Mred, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->snap, (size_t)T * T + T + (size_t)W * T));
+  if (tail_emb_lds_floats(T, e->TP) * sizeof(float) > 48 * 1024)
+    HIP_TRY(e, hipFuncSetAttribute((const void*)k_tail_emb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tail_emb_lds_floats(T, e->TP) * sizeof(float))));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int c = 0; c < 3; ++c) {
@@ -1060,9 +1075,9 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
 int sdrm_destroy(sdrm_engine* e) {
   if (!e) return SDRM_ERR_ARG;
   (void)hipSetDevice(e->device);
-  void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->Etab, e->B0tab,
+  void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->tembP, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->dC0, e->dE, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1156,35 +1171,32 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
 
+  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false;
   if (skinny_net(e)) {
-    // narrow net: tables (B0tab = b0 + C0[t], E for the embedding backward), then staging and all layers in one launch
-    int rc = emb_tables(e, true, st);
+    // narrow net (csrc/skinny_step.h): staging, all layers and the loss partial sums of 16 users' P, S, Q rows per work-group in
+    // ONE launch; the tables B0tab = b0 + C0[t] come from the last step's tail (or are made now, after a parameter upload)
+    int rc = ensure_tables(e, st);
     if (rc) return rc;
-    SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
+    SkStepArgs ka = sk_step_args(e, B);
     ka.x0 = x0;
     if (mode == SDRM_RNG_EXPLICIT) { ka.noise = rnd->noise; ka.t = rnd->t; ka.keep = rnd->keep; }
     ka.mode = mode; ka.seed_lo = (uint32_t)seed; ka.seed_hi = (uint32_t)(seed >> 32); ka.step = (uint32_t)step;
     ka.row0 = row0; ka.nd = nd;
-    rc = launch_skinny_train(e, ka, 0, st);
+    rc = launch_sk_step(e, ka, 0, ka.G, st);
     if (rc) return rc;
-    LossArgs la{};
-    la.Y = e->Y; la.x0 = x0; la.B = B; la.L = e->L; la.LP = e->LP; la.part = e->loss_part;
-    SDRM_LAUNCH(e, k_loss_partials, dim3(LOSS_BLOCKS), dim3(1024), 0, st, la);
-    HIP_TRY(e, hipGetLastError());
     if (!e->fold_sums) {
-      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, LOSS_BLOCKS,
-                         (double)B * (double)e->L, sums ? sums : e->sums);
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, ka.G, (double)B * (double)e->L,
+                         sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
-    e->cur_B = B; e->cur_MP = MP; e->cur_x0 = x0; e->fwd_done = true;
+    e->cur_B = B; e->cur_MP = round_up(SK_ROWS * ka.G, BM); e->cur_x0 = x0; e->cur_sk = true; e->fwd_done = true;
     return SDRM_OK;
   }
 
-  e->cur_grouped = false; e->cur_act = false;
   if (use_rowchain(e, B)) {
     // row-owned forward (rowchain.h): the step's tables (the launch also pulls the batch into L2), then staging + every layer +
     // the loss partial sums in ONE launch
-    int rc = emb_tables(e, true, st, x0, (size_t)B * e->L);
+    int rc = emb_tables(e, st, x0, (size_t)B * e->L);
     if (rc) return rc;
     const int G = (B + RC_USERS - 1) / RC_USERS, MPg = round_up(G * RC_ROWS, BM);
     rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st);
@@ -1201,7 +1213,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   PrepTrainArgs pa{};
   pa.x0 = x0;
   if (mode == SDRM_RNG_EXPLICIT) { pa.noise = rnd->noise; pa.t = rnd->t; pa.keep = rnd->keep; }
-  pa.sqrt_ab = e->sched + 3 * n; pa.one_minus_ab = e->sched + 4 * n;
+  pa.sqrt_ab = e->sched + 3 * n; pa.one_minus_ab = e->sched + 4 * n; pa.tembP = e->tembP;
   pa.U = e->U; pa.tdev = e->tdev;
   pa.B = B; pa.L = e->L; pa.LP = e->LP; pa.K0 = e->K0; pa.T = e->T; pa.MP = MP;
   pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
@@ -1209,7 +1221,8 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   {
     // the step's tables ride on the staging launch: E (embedding backward), C0^T in the trailing columns of W0c (what the
     // plain-forward path multiplies the one-hot columns with) and B0tab = b0 + C0[t], which layer 0 below adds per row
-    pa.emb = emb_args(e, true);
+    pa.emb = emb_args(e);
+    e->tables_fresh = true;
     pa.emb_row0 = B + (MP - 3 * B);
     pa.emb_blocks = e->T + 1;
     const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
@@ -1263,11 +1276,11 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   e->bwd_strips = false;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
-  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_grouped ? 1 : 0;
+  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0);
   sa.part = e->loss_part; sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
   // the row-owned chain (dgrad_rows.h) computes the seeds itself; every other path launches k_loss_seed
   const bool chain = use_dgrad_rows(e, MP) && e->tune.dgrad_rows == 1 && H + 1 <= DR_MAX_LAYERS;
-  if (!chain) {
+  if (!chain && !e->cur_sk) {
     const int nslots = e->cur_grouped ? RC_USERS * ((B + RC_USERS - 1) / RC_USERS) : B;
     const unsigned need = (unsigned)(((size_t)(nslots + (MP - 3 * nslots)) * (e->LP / 4) + 255) / 256);
     dim3 grid(std::min(need, 2048u));   // grid-stride beyond: see k_loss_seed
@@ -1285,17 +1298,18 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   const int dgrad_blocks = ((MP + kCfgBM[cfg_d] - 1) / kCfgBM[cfg_d]) * ((e->WP + kCfgBN[cfg_d] - 1) / kCfgBN[cfg_d]);
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
-  if (skinny_net(e)) {
-    // narrow net: the whole dgrad chain in one launch; one slope partial per application and work-group
-    const SkinnyTrainArgs ka = skinny_train_args(e, B, MP);
-    int rc = launch_skinny_train(e, ka, 1, st);
+  e->bwd_hidden_apps = H;
+  if (e->cur_sk) {
+    // narrow net (csrc/skinny_step.h): the sums' fold, the loss value, the seeds, the whole dgrad chain AND every weight / bias /
+    // slope gradient of a work-group's users in one launch; one slab set per work-group (the hidden layer's applications already
+    // summed), at most S_MAX of them - a work-group then walks several groups of users
+    SkStepArgs ka = sk_step_args(e, B);
+    ka.x0 = e->cur_x0; ka.sums = sa.sums; ka.count = sa.count; ka.loss = loss;
+    const int S = std::min(ka.G, S_MAX);
+    int rc = launch_sk_step(e, ka, 1, S, st);
     if (rc) return rc;
-    if (with_wgrad0)
-      HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
-                                      Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
-    e->bwd_kc0 = kc0;
-    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = MP / 16;
-    e->bwd_kcH = kcH; e->bwd_kcO = kcO;
+    e->bwd_S0 = e->bwd_SH = e->bwd_SO = S; e->bwd_hidden_apps = 1; e->bwd_dgrad_blocks = S;
+    e->bwd_kc0 = e->bwd_kcH = e->bwd_kcO = 0;
     return SDRM_OK;
   }
   if (use_dgrad_rows(e, MP)) {
@@ -1346,6 +1360,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
 // dgrad chain is done.  More problems than a batch holds (H > 6) go in several batches; a forced tile shape
 // (SDRM_TILE) falls back to one launch per layer.
 int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
+  if (e->cur_sk) return SDRM_OK;   // the narrow nets' backward launch has left every weight gradient in its slabs
   const int B = e->cur_B, MP = e->cur_MP, H = e->H, SH = e->bwd_SH, SO = e->bwd_SO;
   const double flO = 2.0 * 3 * B * (double)e->L * e->W, flH = 2.0 * 3 * B * (double)e->W * e->W;
   const double fl0 = 2.0 * 3 * B * (double)e->W * (e->L + e->T);
@@ -1390,32 +1405,98 @@ int backward_wgrads(sdrm_engine* e, hipStream_t st, bool with_wgrad0) {
 
 enum { BUCKET_FIRST = 1, BUCKET_SECOND = 2, BUCKET_BOTH = 3 };
 
-// slab reduction into the flat gradient (written where the caller wants it, e.g. a DDP bucket - no copy afterwards)
-int backward_finalize(sdrm_engine* e, float* gout, int which, hipStream_t st) {
-  JobTable tab;
-  build_jobs(e, tab, e->bwd_S0, e->bwd_SH, e->bwd_SO, e->bwd_dgrad_blocks, gout, e->bwd_strips ? e->ones_col : -1);
-  JobTable sel{};
-  for (int j = 0; j < tab.n; ++j) {
-    const bool second = tab.j[j].gdst >= gout + e->off_a0 && tab.j[j].gdst < gout + e->P;
-    if ((second && (which & BUCKET_SECOND)) || (!second && (which & BUCKET_FIRST))) sel.j[sel.n++] = tab.j[j];
+// The tail of a backward (csrc/tail.h): slabs -> flat gradient (written where the caller wants it, e.g. a DDP bucket - no copy
+// afterwards), the embedding path's gradients from the time-embedding columns of the layer-0 slabs, and - `update` (the
+// single-GPU step) - Adam straight from the sums with the re-pack of the compute copies: ONE launch for everything that needs
+// only the slabs, a second for the embedding path (FIRST bucket: W0e and emb_layer.*, out of what the first launch left).
+int backward_tail(sdrm_engine* e, float* gout, int which, bool update, float lr, hipStream_t st) {
+  const int L = e->L, W = e->W, T = e->T, H = e->H;
+  const int S0 = e->bwd_S0, SH = e->bwd_SH, SO = e->bwd_SO;
+  const int bias_col = e->bwd_strips ? e->ones_col : -1;   // strip-owned weight gradients: the bias gradient is slab column ones_col
+  TailArgs a{};
+  int n = 0, blocks = 0;
+  auto add = [&](int kind, int64_t off, int rows, int cols, int flat_ld, const float* src, int src_ld, size_t slab_stride, int nslabs,
+                 int nblocks) -> TailJob& {
+    TailJob& j = a.j[n];
+    j.kind = kind; j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld;
+    j.src = src; j.src_ld = src_ld; j.slab_stride = slab_stride; j.nslabs = nslabs; j.inner = 1; j.nblocks = nblocks; j.lanes = 4;
+    j.red = nullptr; j.red_ld = 0;
+    j.dst = j.dstT = j.dstF = j.dstFT = nullptr; j.dst_ld = j.dstT_ld = 0; j.fnct = e->WP / 16; j.fklast = j.fklastT = -1;
+    a.start[n++] = blocks;
+    blocks += nblocks;
+    return j;
+  };
+  // a weight's sub-tiles: 8 x 32 with four lanes per column quad (each a quarter of the slabs) when there are more than eight slabs,
+  // else 32 x 32 with one (csrc/tail.h)
+  auto mat = [&](int64_t off, int rows, int cols, int flat_ld, const float* src, int src_ld, size_t slab_stride, int nslabs) -> TailJob& {
+    const int lanes = nslabs > 8 ? 4 : 1, tr = lanes == 4 ? 8 : 32;
+    TailJob& j = add(TJ_MAT, off, rows, cols, flat_ld, src, src_ld, slab_stride, nslabs, ((rows + tr - 1) / tr) * ((cols + 31) / 32));
+    j.lanes = lanes;
+    return j;
+  };
+  auto vec = [&](int64_t off, int len, const float* col_src, int col_ld, size_t col_stride, const float* sum_src, size_t sum_stride, int nslabs,
+                 float* dst) -> TailJob& {
+    TailJob& j = bias_col >= 0 ? add(TJ_VEC, off, len, 1, 1, col_src + bias_col, col_ld, col_stride, nslabs, (len + 63) / 64)
+                               : add(TJ_VEC, off, len, 1, 1, sum_src, 1, sum_stride, nslabs, (len + 63) / 64);   // 64 entries per work-group
+    j.dst = dst;
+    return j;
+  };
+  auto snap = [&](int64_t off, int rows, int cols, int flat_ld, float* dst, int dst_ld) {
+    TailJob& j = add(TJ_SNAP, off, rows, cols, flat_ld, nullptr, 0, 0, 0, (int)(((int64_t)rows * cols + TAIL_THREADS * 8 - 1) / (TAIL_THREADS * 8)));
+    j.red = dst; j.red_ld = dst_ld;
+  };
+  if (which & BUCKET_FIRST) {
+    {
+      TailJob& j = mat(e->off_w0, W, L, L + T, e->slab0, e->K0, (size_t)e->WP * e->K0, S0);
+      j.dst = e->W0c; j.dst_ld = e->K0; j.dstF = e->W0f; j.fklast = rc_light_klast(L, e->LP);
+    }
+    vec(e->off_b0, W, e->slab0, e->K0, (size_t)e->WP * e->K0, e->db0s, (size_t)e->WP, S0, e->b0c);
+    // for the second launch: M = the time-embedding columns of the layer-0 slabs, summed; emb_layer.* and W0e as they are now
+    {
+      TailJob& j = mat(0, W, T, 0, e->slab0 + e->LP, e->K0, (size_t)e->WP * e->K0, S0);
+      j.red = e->Mred; j.red_ld = e->TP;
+    }
+    snap(e->off_we, 1, T * T + T, 0, e->snap, 0);
+    snap(e->off_w0 + L, W, T, L + T, e->snap + (size_t)T * T + T, T);
   }
-  SDRM_LAUNCH(e, k_grad_finalize, dim3(512, sel.n), dim3(256), 0, st, sel);
+  if (which & BUCKET_SECOND) {
+    // PReLU slopes: per-work-group partials of the dgrad epilogues, [application][alpha_part_stride]
+    {
+      TailJob& j = add(TJ_SCALAR, e->off_a0, 1, 1, 1, e->alpha_part, 0, (size_t)e->alpha_part_stride, 1, 1);
+      j.inner = e->bwd_dgrad_blocks;
+    }
+    if (H >= 1) {
+      const int HS = e->bwd_hidden_apps * SH;   // slab sets of the shared hidden layer: one per application and K-slice, or per K-slice
+      TailJob& j = mat(e->off_wh, W, W, W, e->slabH, e->WP, (size_t)e->WP * e->WP, HS);
+      j.dst = e->Whc; j.dst_ld = e->WP; j.dstT = e->WhcT; j.dstT_ld = e->WP; j.dstF = e->Whf; j.dstFT = e->WhfT;
+      j.fklast = j.fklastT = rc_light_klast(W, e->WP);
+      vec(e->off_bh, W, e->slabH, e->WP, (size_t)e->WP * e->WP, e->dbHs, (size_t)e->WP, HS, e->bhc);
+      TailJob& s = add(TJ_SCALAR, e->off_ah, 1, 1, 1, e->alpha_part + e->alpha_part_stride, 0, (size_t)e->alpha_part_stride, H, 1);
+      s.inner = e->bwd_dgrad_blocks;
+    }
+    {
+      TailJob& j = mat(e->off_wo, L, W, W, e->slabO, e->WP, (size_t)e->LP * e->WP, SO);
+      j.dst = e->Woc; j.dst_ld = e->WP; j.dstT = e->WocT; j.dstT_ld = e->LP; j.dstF = e->Wof; j.dstFT = e->WofT;
+      j.fklast = rc_light_klast(W, e->WP); j.fklastT = rc_light_klast(L, e->LP);
+    }
+    vec(e->off_bo, L, e->slabO, e->WP, (size_t)e->LP * e->WP, e->dbOs, (size_t)e->LP, SO, e->boc);
+  }
+  a.start[n] = blocks;
+  a.n = n;
+  a.p = e->p; a.m = e->m; a.v = e->v; a.g = gout;
+  a.L = L; a.W = W; a.T = T; a.LP = e->LP; a.TP = e->TP;
+  a.off_we = e->off_we; a.off_be = e->off_be; a.off_w0 = e->off_w0; a.off_b0 = e->off_b0;
+  a.Mred = e->Mred; a.snap = e->snap;
+  a.b1 = 0.9f; a.b2 = 0.999f; a.eps = 1e-8f; a.wd = 1e-4f; a.update = update ? 1 : 0;
+  if (update) adam_scalars(e, lr, a.step_size, a.bc2_sqrt);
+  SDRM_LAUNCH(e, k_tail, dim3((unsigned)blocks), dim3(TAIL_THREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
-  return SDRM_OK;
-}
-
-// embedding backward from dC0 (needs the first bucket's finalize): gradients of emb_layer.weight / .bias
-int backward_embedding(sdrm_engine* e, float* gout, hipStream_t st) {
-  EmbBwdArgs ea{};
-  ea.dC0T = e->dC0; ea.TP = e->TP;
-  ea.W0 = e->p + e->off_w0; ea.Etab = e->Etab; ea.temb = e->temb; ea.dE = e->dE; ea.g = gout;
-  ea.off_we = e->off_we; ea.off_be = e->off_be; ea.off_w0 = e->off_w0;
-  ea.L = e->L; ea.W = e->W; ea.T = e->T;
-  SDRM_LAUNCH(e, k_emb_bwd1, dim3(e->T + 1 + (e->W * e->T + 255) / 256), dim3(1024), 0, st, ea);
-  HIP_TRY(e, hipGetLastError());
-  const int items = e->T * e->T + e->T;
-  SDRM_LAUNCH(e, k_emb_bwd2, dim3((items + 63) / 64), dim3(256), 0, st, ea);   // four lanes per output
-  HIP_TRY(e, hipGetLastError());
+  if (update) e->tables_fresh = false;
+  if (which & BUCKET_FIRST) {
+    const int eb = tail_emb_blocks_a(W, T) + tail_emb_blocks_b(T) + 1;
+    SDRM_LAUNCH(e, k_tail_emb, dim3((unsigned)eb), dim3(256), tail_emb_lds_floats(T, e->TP) * sizeof(float), st, a);
+    HIP_TRY(e, hipGetLastError());
+  }
   return SDRM_OK;
 }
 
@@ -1429,8 +1510,7 @@ int sdrm_train_backward_begin(sdrm_engine* e, const double* sums, float* grad, f
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
   int rc = backward_chain(e, sums, loss, st, true);
-  if (!rc) rc = backward_finalize(e, gout, BUCKET_FIRST, st);
-  if (!rc) rc = backward_embedding(e, gout, st);
+  if (!rc) rc = backward_tail(e, gout, BUCKET_FIRST, false, 0.f, st);
   if (rc) return rc;
   e->bwd_begun = true;
   return SDRM_OK;
@@ -1443,24 +1523,27 @@ int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
   float* gout = grad ? grad : e->g;
   if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_finish: different gradient buffer than begin");
   int rc = backward_wgrads(e, st, false);
-  if (!rc) rc = backward_finalize(e, gout, BUCKET_SECOND, st);
+  if (!rc) rc = backward_tail(e, gout, BUCKET_SECOND, false, 0.f, st);
   e->bwd_begun = false;
   return rc;
 }
 
-// the whole backward in one call: same kernels, one slab reduction for both buckets
-int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
-  if (!e) return SDRM_ERR_ARG;
-  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
-  hipStream_t st = (hipStream_t)stream;
+// the whole backward in one call: same kernels, one tail for both buckets; `fused_lr` (the single-GPU step): Adam applied by the
+// tail itself, straight from the slab sums (the flat gradient is still written: sdrm_get_grads)
+static int train_backward_impl(sdrm_engine* e, const double* sums, float* grad, float* loss, hipStream_t st, const float* fused_lr) {
   e->bwd_begun = false;
   float* gout = grad ? grad : e->g;
   e->grad_src = gout;
   int rc = backward_chain(e, sums, loss, st, false);
   if (!rc) rc = backward_wgrads(e, st, true);
-  if (!rc) rc = backward_finalize(e, gout, BUCKET_BOTH, st);
-  if (!rc) rc = backward_embedding(e, gout, st);
+  if (!rc) rc = backward_tail(e, gout, BUCKET_BOTH, fused_lr != nullptr, fused_lr ? *fused_lr : 0.f, st);
   return rc;
+}
+
+int sdrm_train_backward(sdrm_engine* e, const double* sums, float* grad, float* loss, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  if (!e->fwd_done) return fail(e, SDRM_ERR_STATE, "sdrm_train_backward: no forward to back-propagate");
+  return train_backward_impl(e, sums, grad, loss, (hipStream_t)stream, nullptr);
 }
 
 int sdrm_grad_buckets(const sdrm_engine* e, int64_t* first_off, int64_t* first_len, int64_t* second_off, int64_t* second_len) {
@@ -1480,12 +1563,16 @@ int sdrm_adam_step(sdrm_engine* e, const float* grad, float lr, void* stream) {
 int sdrm_train_step(sdrm_engine* e, const float* x0, int B, float lr, int mode, const sdrm_train_randoms* rnd,
                     uint64_t seed, uint64_t step, float nd, float* loss, void* stream) {
   if (!e) return SDRM_ERR_ARG;
-  e->fold_sums = true;    // one process, one GPU: nobody needs the five sums between the forward and the backward
+  e->fold_sums = true;    // one process, one GPU: nobody needs the five sums between the forward and the backward ...
   int rc = sdrm_train_forward(e, x0, B, 0, mode, rnd, seed, step, nd, nullptr, stream);
-  if (!rc) rc = sdrm_train_backward(e, nullptr, nullptr, loss, stream);
   e->fold_sums = false;
   if (rc) return rc;
-  return sdrm_adam_step(e, nullptr, lr, stream);
+  e->fold_sums = true;
+  e->adam_t += 1;         // ... nor the flat gradient between the backward and Adam: the tail applies it (csrc/tail.h)
+  rc = train_backward_impl(e, nullptr, nullptr, loss, (hipStream_t)stream, &lr);
+  e->fold_sums = false;
+  if (rc) e->adam_t -= 1;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1627,7 +1714,7 @@ int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_train_outputs: no forward yet");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
-                     e->LP, e->cur_grouped ? 1 : 0, psq);
+                     e->LP, e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0), psq);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }
@@ -1648,7 +1735,7 @@ static int forward_rows(sdrm_engine* e, const float* x, const int64_t* t, int t_
   dim3 grid((unsigned)((size_t)pa.bpr * MP));
   SDRM_LAUNCH(e, k_prep_forward, grid, dim3(256), 0, st, pa);
   HIP_TRY(e, hipGetLastError());
-  int rc = emb_tables(e, false, st);
+  int rc = ensure_tables(e, st);
   if (rc) return rc;
   {
     GemmArgs a{};
@@ -1755,7 +1842,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   e->n_chains = chains_for(e->tune, n);
   e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
-  int rc = emb_tables(e, true, st);
+  int rc = ensure_tables(e, st);
   if (rc) return rc;
   int i_start = T;
   e->smp_nact.assign(T + 2, n);                       // n_act[i] = rows with Tj >= i (all rows when full resolution)
@@ -1951,7 +2038,7 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
   if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
-                     e->cur_B, e->W, e->WP, e->cur_grouped ? 1 : 0, out);
+                     e->cur_B, e->W, e->WP, e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0), out);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }

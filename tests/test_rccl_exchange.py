@@ -88,3 +88,74 @@ def test_explicit_randoms_through_the_sharded_step(engine_cls):
     lb = float(b.train_step_sharded(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
     assert la == lb and bool((a.get_params() == b.get_params()).all())
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Two REAL ranks over RCCL: needs two devices, so it skips itself on a one-GPU box and runs wherever a multi-GPU driver
+# runs `pytest -m gpu` (the first N > 1 execution of sdrm_comm_init_rank / sdrm_train_step_sharded
+# should be a test, not the scaling bench).
+def _rccl_worker(rank, world, port, init_flat, x0, dims, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # carries the 128-byte unique id only
+    from sdrm_amd.engine import Engine
+    from sdrm_amd.parallel import RcclTrainer, shard_rows
+    gl, gw, gt, gh, gb = dims
+    eng = Engine(gl, gw, gt, gh, max_rows=gb)
+    eng.set_params(init_flat)
+    tr = RcclTrainer(eng, rank, world)
+    info = eng.comm_info()
+    r0, rows = shard_rows(gb, rank, world)
+    losses = []
+    for step in range(3):
+        loss = tr.train_step(torch.from_numpy(x0[r0:r0 + rows]).cuda(), 2e-3 * (1 - step / 3), row0=r0, step=step, seed=4242, nd=0.9)
+        losses.append(float(loss.cpu()))
+    q.put((rank, info, eng.get_params().cpu().numpy(), losses))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dims", [(340, 340, 78, 1, 2048), (40, 40, 93, 5, 107)])
+def test_two_rank_rccl_step_equals_one_rank(dims):
+    """Two processes, two devices, the library's own communicator (sdrm_comm_unique_id -> sdrm_comm_init_rank) and
+    sdrm_train_step_sharded: comm_info() == (2, rank) on both, the three-step trajectory equals the single-engine
+    sdrm_train_step to 1e-5 (fp32 summation order of the two half-batches), and the replicas stay bit-identical."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from sdrm_amd.engine import Engine
+    gl, gw, gt, gh, gb = dims
+    init_flat = synth.flatten_params(synth.init_params(gl, gw, gt, gh, seed=13), gh)
+    x0 = synth.synth_latents(gb, gl, seed=14)
+    single = Engine(gl, gw, gt, gh, max_rows=gb)
+    single.set_params(init_flat)
+    ref_losses = [float(single.train_step(x0, 2e-3 * (1 - s / 3), seed=4242, step=s, nd=0.9).cpu()) for s in range(3)]
+    ref = single.get_params().cpu().numpy()
+    single.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, init_flat, x0, dims, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, info, flat, losses in results:
+        assert tuple(info) == (2, rank)
+        assert np.sqrt(((flat - ref) ** 2).sum() / (ref ** 2).sum()) < 1e-5, rank
+        np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    assert np.array_equal(results[0][2], results[1][2])
