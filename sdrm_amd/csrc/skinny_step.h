@@ -51,7 +51,9 @@ struct SkStepArgs {
   float* slab0; float* slabH; float* slabO;        // [S][WPs][K0], [S][WPs][WPs], [S][LPs][WPs]: S = gridDim.x slab sets
   float* db0s; float* dbHs; float* dbOs;           // [S][WPs], [S][WPs], [S][LPs]
   float* alpha_part; int alpha_part_stride;        // [application][alpha_part_stride], entry = work-group
+  unsigned long long* stamps;                      // diagnostic runs only (SDRM_SK_STAMPS): 16 s_memtime slots per work-group
 };
+#define SK_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[16 * (size_t)blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int NL, int NW>
 struct SkCfg {
@@ -65,7 +67,7 @@ struct SkCfg {
 // dynamic LDS (floats): forward: two tiles; backward: two gradient tiles, two input tiles, the pass-summed dpre0 tile [16][SCR],
 // the users' time-embedding rows [16][TPs + 4], bias column sums [3 kinds][3 passes][64], slope partials [32 applications][12 waves]
 template <int NL, int NW>
-__host__ __device__ constexpr size_t sk_fwd_lds_floats() { return 2 * (size_t)SkCfg<NL, NW>::TILE + 16 + 2 * 4 * 12; }   // + trow [16], loss sums [12 waves][4] doubles
+__host__ __device__ constexpr size_t sk_fwd_lds_floats() { return 2 * (size_t)SkCfg<NL, NW>::TILE + 16 + 2 * 4 * 12 + 16 * (size_t)SkCfg<NL, NW>::SCR; }   // + trow [16], loss sums [12 waves][4] doubles, x0 [16][SCR]
 template <int NL, int NW>
 __host__ __device__ inline size_t sk_bwd_lds_floats(int TPs) {
   return 4 * (size_t)SkCfg<NL, NW>::TILE + SK_USERS * (size_t)SkCfg<NL, NW>::SCR + SK_USERS * (size_t)(TPs + 4) + 3 * 3 * 64 + 32 * 12 + 64;
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
   float* tile1 = sksh + C::TILE;
   int* trow = reinterpret_cast<int*>(sksh + 2 * C::TILE);          // [16]
   double* red = reinterpret_cast<double*>(sksh + 2 * C::TILE + 16);   // [12 waves][4] (8-byte aligned: TILE is a multiple of 4 floats)
+  float* x0s = sksh + 2 * C::TILE + 16 + 2 * 4 * 12;                   // [16][SCR]: the group's x0 rows (loss sums)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pass = wave / NV, ct = wave - pass * NV;
@@ -101,64 +104,84 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
   }
   const float slope0 = *a.slope0, slopeh = a.H > 0 ? *a.slopeh : 0.f;
 
+  SK_STAMP(0);
   for (int g = blockIdx.x; g < a.G; g += gridDim.x) {
     const int u0 = SK_USERS * g;
     const size_t grow0 = (size_t)SK_ROWS * g;
-    // ---- staging: lane -> (user lane / 4, column quad ct * 4 + lane % 4); the three pass waves of a column tile draw the same
-    // Philox words (the noise is shared by the passes, the keep bits are bits 0..2 of the same words)
-    if (ct < NL) {
-      const int ur = lane >> 2, c0 = ct * 16 + 4 * (lane & 3);
-      const int usr = u0 + ur;
-      int t0 = 0;
-      f32x4 uv = {0.f, 0.f, 0.f, 0.f};
-      if (usr < a.B) {
+    // ---- requests first: a work-group is a chain of dependent memory round trips (about 2 us each), so everything the staging
+    // needs is asked for before anything is computed.  Staging lane -> (user lane / 4, column quad ct * 4 + lane % 4).
+    const int ur = lane >> 2, c0 = ct * 16 + 4 * (lane & 3);
+    const int usr = u0 + ur;
+    const bool stg = ct < NL && usr < a.B;
+    float xs[4] = {0.f, 0.f, 0.f, 0.f}, ens[4] = {0.f, 0.f, 0.f, 0.f};
+    bool kps[4] = {false, false, false, false};
+    if (stg) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = c0 + j;
+        if (cc < a.L) {
+          const size_t idx = (size_t)usr * a.L + cc;
+          xs[j] = a.x0[idx];
+          if (a.mode == 0) { ens[j] = a.noise[idx]; kps[j] = a.keep[(size_t)pass * a.B * a.L + idx] != 0; }
+        }
+      }
+    }
+    if (tid < SK_USERS) {   // the 16 users' timesteps (train_SDRM.py:327), once per work-group
+      const int uu = u0 + tid;
+      int t0 = -1;
+      if (uu < a.B) {
         if (a.mode == 0) {
-          t0 = (int)a.t[usr];
+          t0 = (int)a.t[uu];
         } else {
-          const U4 w = philox4x32_10((uint32_t)(a.row0 + usr), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
+          const U4 w = philox4x32_10((uint32_t)(a.row0 + uu), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
           t0 = 1 + (int)bounded(w.x, (uint32_t)a.T);
         }
         t0 = min(max(t0, 0), a.T);
-        float ee[4] = {0.f, 0.f, 0.f, 0.f};
-        uint32_t bits[4] = {0u, 0u, 0u, 0u};
+        a.tdev[uu] = t0;
+      }
+      trow[tid] = t0;
+    }
+    lds_barrier();
+    SK_STAMP(1);
+    // layer 0's time-embedding term + bias: the table row of each accumulator row's timestep - in flight under the staging
+    float b0v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ct < NW) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b0v[r] = a.B0tab[(size_t)max(trow[4 * lq + r], 0) * a.WPs + col];
+    }
+    // ---- staging: the three pass waves of a column tile draw the same Philox words (the noise is shared by the passes, the keep
+    // bits are bits 0..2 of the same words)
+    if (ct < NL) {
+      f32x4 uv = {0.f, 0.f, 0.f, 0.f};
+      if (stg) {
+        const int t0 = trow[ur];
         if (a.mode != 0 && c0 < a.L) {
           const U4 w = philox4x32_10((uint32_t)(a.row0 + usr), (uint32_t)(c0 >> 2), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo, a.seed_hi);
-          box_muller(w.x, w.y, ee[0], ee[1]);
-          box_muller(w.z, w.w, ee[2], ee[3]);
-          bits[0] = w.x; bits[1] = w.y; bits[2] = w.z; bits[3] = w.w;
+          box_muller(w.x, w.y, ens[0], ens[1]);
+          box_muller(w.z, w.w, ens[2], ens[3]);
+          const uint32_t bits[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ens[j] *= a.nd; kps[j] = (bits[j] >> pass) & 1u; }
         }
         const float sa = a.sqrt_ab[t0], sb = a.one_minus_ab[t0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int cc = c0 + j;
-          if (cc < a.L) {
-            const size_t idx = (size_t)usr * a.L + cc;
-            const float x = a.x0[idx];
-            float e1; bool kp;
-            if (a.mode == 0) {
-              e1 = a.noise[idx];
-              kp = a.keep[(size_t)pass * a.B * a.L + idx] != 0;
-            } else {
-              e1 = ee[j] * a.nd;
-              kp = (bits[j] >> pass) & 1u;
-            }
+          if (c0 + j < a.L) {
+            const float x = xs[j], e1 = ens[j];
             const float v = pass == 0 ? sa * x + sb * e1 : (pass == 1 ? x : x + MU * e1);
-            uv[j] = kp ? 2.f * v : 0.f;
+            uv[j] = kps[j] ? 2.f * v : 0.f;
           }
         }
-        if (wave == 0 && (lane & 3) == 0) a.tdev[usr] = t0;
       }
-      if (wave == 0 && (lane & 3) == 0) trow[ur] = usr < a.B ? t0 : -1;
       *reinterpret_cast<f32x4*>(&tile0[(16 * pass + ur) * SCR + c0]) = uv;
       *reinterpret_cast<f32x4*>(a.U + (grow0 + 16 * pass + ur) * a.K0 + c0) = uv;
+      if (pass == 1) *reinterpret_cast<f32x4*>(&x0s[ur * SCR + c0]) = f32x4{xs[0], xs[1], xs[2], xs[3]};   // x0 for the loss sums
     }
-    __syncthreads();
+    lds_barrier();
+    SK_STAMP(2);
 
-    // ---- layer 0: latent part by MFMA, time-embedding part + bias from the table row of the row's own timestep
+    // ---- layer 0: latent part by MFMA, time-embedding part + bias from the table
     if (ct < NW) {
-      float b0v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) b0v[r] = a.B0tab[(size_t)max(trow[4 * lq + r], 0) * a.WPs + col];
       f32x4 af[NL];
       read_frags<NL, SCR>(tile0 + 16 * pass * SCR, li, lq, af);
       const f32x4 acc = skinny_tile<NL>(af, w0f);
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
         tile1[(16 * pass + 4 * lq + r) * SCR + col] = prelu_f(p, slope0);
       }
     }
-    __syncthreads();
+    lds_barrier();
     float* cur = tile1;
     float* oth = tile0;
     for (int h = 1; h <= a.H; ++h) {   // the shared hidden layer, H applications (Q1)
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
         }
       }
       float* t_ = cur; cur = oth; oth = t_;
-      __syncthreads();
+      lds_barrier();
     }
     // ---- out layer: tanh; Y to memory (the seeds read it) and into the other tile (the loss sums read it)
     if (ct < NL) {
@@ -200,7 +223,8 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
         oth[(16 * pass + 4 * lq + r) * SCR + col] = y;
       }
     }
-    __syncthreads();
+    lds_barrier();
+    SK_STAMP(3);
     // ---- loss partial sums (:196-198): R = P - x0, D = (Q - S) / mu^2 - R, over the group's users and the real columns
     {
       double sD = 0, sC = 0, sR = 0, sR2 = 0;
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
         const int usr = u0 + ur;
         if (usr < a.B && c < a.L) {
           const float P = oth[ur * SCR + c], S = oth[(16 + ur) * SCR + c], Q = oth[(32 + ur) * SCR + c];
-          const float R = P - a.x0[(size_t)usr * a.L + c];
+          const float R = P - x0s[ur * SCR + c];
           const float D = (Q - S) / MU2 - R;
           const float RS = R - S;
           sD += (double)(D * D); sC += (double)(RS * RS); sR += (double)R; sR2 += (double)(R * R);
@@ -225,13 +249,14 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
         for (int j = 0; j < 4; ++j) red[4 * wave + j] = v4[j];
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 4) {
       double s = 0.0;
       for (int w = 0; w < C::NWAVES; ++w) s += red[4 * w + tid];
       a.loss_part[4 * (size_t)g + tid] = s;
     }
-    __syncthreads();   // the next group's staging overwrites the tiles and trow
+    SK_STAMP(4);
+    lds_barrier();   // the next group's staging overwrites the tiles and trow
   }
 }
 
@@ -242,21 +267,30 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
 template <int ROWS>
 __device__ __forceinline__ f32x4 sk_wgrad_tile(const float* __restrict__ D, int ldd, int n0, const float* __restrict__ X, int ldx, int k0,
                                                int li, int lq, f32x4 acc) {
+  // every operand is requested before the first MFMA: read - multiply pairs in program order expose the LDS latency per pair
+  float dv[ROWS / 4], xv[ROWS / 4];
+#pragma unroll
+  for (int g = 0; g < ROWS / 4; ++g) { dv[g] = D[(4 * g + lq) * ldd + n0 + li]; xv[g] = X[(4 * g + lq) * ldx + k0 + li]; }
   f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < ROWS / 4; g += 2) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(D[(4 * g + lq) * ldd + n0 + li], X[(4 * g + lq) * ldx + k0 + li], acc, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(D[(4 * g + 4 + lq) * ldd + n0 + li], X[(4 * g + 4 + lq) * ldx + k0 + li], acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[g], xv[g], acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[g + 1], xv[g + 1], acc1, 0, 0, 0);
   }
   return acc + acc1;
 }
 
-// C-layout tile into a slab: first contribution of this work-group stores, later ones (further groups of the same work-group) add
+// C-layout tile into a slab: the first contribution of this work-group stores, later ones (further groups of the same work-group)
+// add.  Two code paths behind a uniform branch: written as one select the compiler loads the old value on both (a global round
+// trip in front of every tile's stores).
 __device__ __forceinline__ void sk_slab_tile(float* __restrict__ dst, int ld, int n0, int k0, int li, int lq, const f32x4& acc, bool first) {
+  float* p = dst + (size_t)(n0 + 4 * lq) * ld + k0 + li;
+  if (first) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float* p = dst + (size_t)(n0 + 4 * lq + r) * ld + k0 + li;
-    *p = first ? acc[r] : *p + acc[r];
+    for (int r = 0; r < 4; ++r) p[(size_t)r * ld] = acc[r];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[(size_t)r * ld] += acc[r];
   }
 }
 
@@ -294,16 +328,28 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
   if (a.sums) {
     s0 = a.sums[0]; s1 = a.sums[1]; s2 = a.sums[2]; s3 = a.sums[3]; N = a.sums[4];
   } else {
-    double v[4] = {0, 0, 0, 0};
-    for (int i = tid; i < a.G; i += NTHR)
-      for (int j = 0; j < 4; ++j) v[j] += a.loss_part[4 * (size_t)i + j];
-    double* shs = shd;       // [12] scratch of block_sum (one slot per wave), [4] totals
-    for (int j = 0; j < 4; ++j) {
-      const double t = block_sum(v[j], shs);
-      if (tid == 0) shs[12 + j] = t;
+    // The summation tree of k_loss_sums (elementwise.h), so that this fold and that kernel give the same bits: there 256 threads
+    // stride the partials, the sums go down each of the four waves by shuffles, and the waves' results are added in order.  Here
+    // wave 0 plays the four waves one after the other (a work-group of this kernel may have only three); waves whose partials
+    // would all be absent add exact zeros there and are skipped here.
+    double* shs = shd;   // [4] totals
+    if (wave == 0) {
+      double tot[4] = {0, 0, 0, 0};
+      for (int vw = 0; vw < 4 && 64 * vw < a.G; ++vw) {
+        double v[4] = {0, 0, 0, 0};
+        for (int i = 64 * vw + lane; i < a.G; i += 256)
+          for (int j = 0; j < 4; ++j) v[j] += a.loss_part[4 * (size_t)i + j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += __shfl_down(v[j], off, 64);
+        for (int j = 0; j < 4; ++j) tot[j] += v[j];
+      }
+      if (lane == 0)
+        for (int j = 0; j < 4; ++j) shs[j] = tot[j];
     }
-    __syncthreads();
-    s0 = shs[12]; s1 = shs[13]; s2 = shs[14]; s3 = shs[15]; N = a.count;
+    lds_barrier();
+    s0 = shs[0]; s1 = shs[1]; s2 = shs[2]; s3 = shs[3]; N = a.count;
   }
   const double A = s0 / N, Cc = s1 / N, Rbar = s2 / N;
   const double V = (N > 1.0) ? (s3 - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
@@ -314,51 +360,94 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
   const float rbar = (float)Rbar;
   if (s == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + Cc) / den);
 
+  SK_STAMP(0);
   f32x4 accH[TH];
   bool first = true;
   for (int g = blockIdx.x; g < a.G; g += gridDim.x, first = false) {
     const int u0 = SK_USERS * g;
     const size_t grow0 = (size_t)SK_ROWS * g;
-    __syncthreads();   // the previous group is done with every tile
-    // ---- seeds (App. A.5) times tanh' into Dt(0); the users' temb rows into Te; zero the bias / slope accumulators
-    for (int f = tid; f < SK_USERS * C::LPk; f += NTHR) {
+    lds_barrier();   // the previous group is done with every tile
+    // ---- requests first (a work-group is a chain of dependent memory round trips): the forward's outputs and x0 for the seeds,
+    // the pre-activations of the two topmost layers (this lane's accumulator positions), layer 0's input U, the users' timesteps
+    constexpr int NSEED = (SK_USERS * C::LPk + NTHR - 1) / NTHR;
+    float sP[NSEED], sS[NSEED], sQ[NSEED], sX[NSEED];
+#pragma unroll
+    for (int i = 0; i < NSEED; ++i) {
+      const int f = tid + i * NTHR;
       const int ur = f / C::LPk, c = f - ur * C::LPk;
       const int usr = u0 + ur;
-      float gP = 0.f, gS = 0.f, gQ = 0.f;
-      if (usr < a.B && c < a.L) {
-        const size_t y = (grow0 + ur) * a.LPs + c;
-        const float P = a.Y[y], S = a.Y[y + (size_t)16 * a.LPs], Q = a.Y[y + (size_t)32 * a.LPs];
-        const float R = P - a.x0[(size_t)usr * a.L + c];
-        const float D = (Q - S) / MU2 - R;
-        const float gD = cD * D;
-        const float gC = cD * (R - S);
-        const float gV = cV * (R - rbar);
-        gP = (-gD + gC + gV) * (1.f - P * P);
-        gQ = (gD / MU2) * (1.f - Q * Q);
-        gS = (-gD / MU2 - gC) * (1.f - S * S);
-      }
-      Dt(0)[ur * SCR + c] = gP; Dt(0)[(16 + ur) * SCR + c] = gS; Dt(0)[(32 + ur) * SCR + c] = gQ;
+      const bool in = f < SK_USERS * C::LPk && usr < a.B && c < a.L;
+      const size_t y = (grow0 + (in ? ur : 0)) * a.LPs + (in ? c : 0);
+      sP[i] = in ? a.Y[y] : 0.f; sS[i] = in ? a.Y[y + (size_t)16 * a.LPs] : 0.f; sQ[i] = in ? a.Y[y + (size_t)32 * a.LPs] : 0.f;
+      sX[i] = in ? a.x0[(size_t)usr * a.L + c] : 0.f;
     }
-    for (int f = tid; f < SK_USERS * (a.TPs / 4); f += NTHR) {
-      const int ur = f / (a.TPs / 4), q = f - ur * (a.TPs / 4);
-      const int usr = u0 + ur;
-      float4 te = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (usr < a.B) te = *reinterpret_cast<const float4*>(a.tembP + (size_t)a.tdev[usr] * a.TPs + 4 * q);
-      *reinterpret_cast<float4*>(Te + ur * ldte + 4 * q) = te;
-    }
-    for (int f = tid; f < 3 * 3 * 64; f += NTHR) bsum[f] = 0.f;
-    // the input of the out layer, act[H] = prelu(pre[H]), into Xt(0); its pre-activation stays in registers for PReLU'
-    float pv[4] = {0.f, 0.f, 0.f, 0.f};
+    float pv[4] = {0.f, 0.f, 0.f, 0.f}, pv1[4] = {0.f, 0.f, 0.f, 0.f};   // pre[k], pre[k-1] of the chain's current iteration
     if (ct < NW) {
       const float* pk = a.pre + (size_t)a.H * a.pre_stride;
-      const float sl = a.H > 0 ? slopeh : slope0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pv[r] = pk[(grow0 + 16 * pass + 4 * lq + r) * a.WPs + col];
-        Xt(0)[(16 * pass + 4 * lq + r) * SCR + col] = prelu_f(pv[r], sl);
+        const size_t o = (grow0 + 16 * pass + 4 * lq + r) * a.WPs + col;
+        pv[r] = pk[o];
+        if (a.H >= 1) pv1[r] = (pk - a.pre_stride)[o];
       }
     }
-    __syncthreads();
+    f32x4 ureg = {0.f, 0.f, 0.f, 0.f};
+    if (ct < NL) ureg = *reinterpret_cast<const f32x4*>(a.U + (grow0 + 16 * pass + (lane >> 2)) * a.K0 + ct * 16 + 4 * (lane & 3));
+    constexpr int NTE = 4;   // float4 of the users' temb rows per thread: 16 * TPs / 4 <= NTE * NTHR while TPs <= 192 * NV (else a loop)
+    float4 tereg[NTE];
+    {
+      const int tq = a.TPs / 4;
+#pragma unroll
+      for (int i = 0; i < NTE; ++i) {
+        const int f = tid + i * NTHR;
+        const int ur = f / tq, q = f - ur * tq;
+        const bool in = f < SK_USERS * tq && u0 + ur < a.B;
+        tereg[i] = in ? *reinterpret_cast<const float4*>(a.tembP + (size_t)a.tdev[u0 + ur] * a.TPs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    SK_STAMP(1);
+    // ---- seeds (App. A.5) times tanh' into Dt(0); zero the bias accumulators; act[H] into Xt(0)
+#pragma unroll
+    for (int i = 0; i < NSEED; ++i) {
+      const int f = tid + i * NTHR;
+      if (f < SK_USERS * C::LPk) {
+        const int ur = f / C::LPk, c = f - ur * C::LPk;
+        float gP = 0.f, gS = 0.f, gQ = 0.f;
+        if (u0 + ur < a.B && c < a.L) {
+          const float P = sP[i], S = sS[i], Q = sQ[i];
+          const float R = P - sX[i];
+          const float D = (Q - S) / MU2 - R;
+          const float gD = cD * D;
+          const float gC = cD * (R - S);
+          const float gV = cV * (R - rbar);
+          gP = (-gD + gC + gV) * (1.f - P * P);
+          gQ = (gD / MU2) * (1.f - Q * Q);
+          gS = (-gD / MU2 - gC) * (1.f - S * S);
+        }
+        Dt(0)[ur * SCR + c] = gP; Dt(0)[(16 + ur) * SCR + c] = gS; Dt(0)[(32 + ur) * SCR + c] = gQ;
+      }
+    }
+    for (int f = tid; f < 3 * 3 * 64; f += NTHR) bsum[f] = 0.f;
+    if (ct < NW) {
+      const float sl = a.H > 0 ? slopeh : slope0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Xt(0)[(16 * pass + 4 * lq + r) * SCR + col] = prelu_f(pv[r], sl);
+    }
+    {
+      const int tq = a.TPs / 4;
+#pragma unroll
+      for (int i = 0; i < NTE; ++i) {
+        const int f = tid + i * NTHR;
+        if (f < SK_USERS * tq) *reinterpret_cast<float4*>(Te + (f / tq) * ldte + 4 * (f % tq)) = tereg[i];
+      }
+      for (int f = tid + NTE * NTHR; f < SK_USERS * tq; f += NTHR) {   // very long embeddings only
+        const int ur = f / tq, q = f - ur * tq;
+        *reinterpret_cast<float4*>(Te + ur * ldte + 4 * q) =
+            u0 + ur < a.B ? *reinterpret_cast<const float4*>(a.tembP + (size_t)a.tdev[u0 + ur] * a.TPs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    lds_barrier();
+    SK_STAMP(2);
     // ---- out layer: bias gradient = column sums of the seeds; weight gradient dWo[n < L][k < W] = seeds^T * act[H]
     for (int f = tid; f < 3 * C::LPk; f += NTHR) {
       const int p_ = f / C::LPk, c = f - p_ * C::LPk;
@@ -376,16 +465,21 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
     for (int i = 0; i < TH; ++i) accH[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- the chain: iteration k produces dpre[k] (gradient of pre-activation k) from Dt(cur), then the weight gradient of the
     // layer whose OUTPUT is pre[k] (k >= 1: the shared hidden layer, input act[k-1]; k == 0: layer 0, input U)
+    SK_STAMP(3);
     int cur = 0, xc = 0;
-    for (int k = a.H; k >= 0; --k) {
-      float pvn[4] = {0.f, 0.f, 0.f, 0.f};
+    float ss_h = 0.f, ss_0 = 0.f, cs_h = 0.f, cs_0 = 0.f;
+    // one iteration; (P0, P1, P2) = (pre[k], pre[k-1], pre[k-2]): P0 is this layer's PReLU', P1 the next layer input, P2 is requested
+    // here and first used a whole iteration later.  The three register sets rotate through the roles (three-way unrolled loop below):
+    // a register copy at the end of the iteration would wait for P2's loads right here
+    auto chain_iter = [&](int k, float (&pv)[4], float (&pv1)[4], float (&pv2)[4]) __attribute__((always_inline)) {
       if (ct < NW) {
-        // the next layer input first (loads in flight under the MFMAs): act[k-1] = prelu(pre[k-1]), or U for layer 0
-        if (k >= 1) {
-          const float* pk = a.pre + (size_t)(k - 1) * a.pre_stride;
+        // two layers ahead: pre[k-2] is requested now, used as the layer input of the next iteration (loads never sit on the chain)
+        if (k >= 2) {
+          const float* pk = a.pre + (size_t)(k - 2) * a.pre_stride;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pvn[r] = pk[(grow0 + 16 * pass + 4 * lq + r) * a.WPs + col];
+          for (int r = 0; r < 4; ++r) pv2[r] = pk[(grow0 + 16 * pass + 4 * lq + r) * a.WPs + col];
         }
+        if (k >= a.H - 1) SK_STAMP(6 + 3 * (a.H - k));
         f32x4 acc;
         if (k == a.H) {
           f32x4 af[NL];
@@ -397,6 +491,9 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
           acc = skinny_tile<NW>(af, whT);
         }
         const float sl = k > 0 ? slopeh : slope0;
+        // slope gradient (sum of v * min(pre, 0)) and bias gradient (column sums of d): per-lane sums here - the shared hidden
+        // layer's over all its applications - reduced through the wave ONCE behind the chain (six dependent cross-lane steps per
+        // iteration were a third of it)
         float ssum = 0.f, csum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -407,30 +504,18 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
           csum += d;
           Dt(cur ^ 1)[(16 * pass + 4 * lq + r) * SCR + col] = d;
         }
-        // bias gradient: column sum over this wave's 16 rows (the four lane groups hold four rows each)
-        csum += __shfl_xor(csum, 16, 64);
-        csum += __shfl_xor(csum, 32, 64);
-        if (lq == 0) bsum[((k > 0 ? 1 : 2) * 3 + pass) * 64 + col] += csum;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ssum += __shfl_down(ssum, off, 64);
-        if (lane == 0) red[k * 12 + wave] = ssum;
-        if (k >= 1) {
+        if (k > 0) { ss_h += ssum; cs_h += csum; } else { ss_0 = ssum; cs_0 = csum; }
+        if (k >= 1) {   // the next layer input: act[k-1] = prelu(pre[k-1])
           const float sln = k - 1 > 0 ? slopeh : slope0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            Xt(xc ^ 1)[(16 * pass + 4 * lq + r) * SCR + col] = prelu_f(pvn[r], sln);
-            pv[r] = pvn[r];
-          }
+          for (int r = 0; r < 4; ++r) Xt(xc ^ 1)[(16 * pass + 4 * lq + r) * SCR + col] = prelu_f(pv1[r], sln);
         }
-      } else if (lane == 0) {
-        red[k * 12 + wave] = 0.f;
       }
-      if (k == 0 && ct < NL) {   // layer 0's input: the dropped-out latents the forward stored
-        const int ur = lane >> 2, c0 = ct * 16 + 4 * (lane & 3);
-        *reinterpret_cast<f32x4*>(&Xt(xc ^ 1)[(16 * pass + ur) * SCR + c0]) =
-            *reinterpret_cast<const f32x4*>(a.U + (grow0 + 16 * pass + ur) * a.K0 + c0);
-      }
-      __syncthreads();
+      if (k == 0 && ct < NL)   // layer 0's input: the dropped-out latents the forward stored (requested at the top)
+        *reinterpret_cast<f32x4*>(&Xt(xc ^ 1)[(16 * pass + (lane >> 2)) * SCR + ct * 16 + 4 * (lane & 3)]) = ureg;
+      if (k >= a.H - 1) SK_STAMP(7 + 3 * (a.H - k));
+      lds_barrier();
+      if (k >= a.H - 1) SK_STAMP(8 + 3 * (a.H - k));
       if (k >= 1) {
         for (int i = 0; i < TH; ++i) {
           const int tl = wave + i * NWAVES;
@@ -452,8 +537,29 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
         }
       }
       cur ^= 1; xc ^= 1;
+    };
+    {
+      float pvc[4] = {0.f, 0.f, 0.f, 0.f};
+      int k = a.H;
+      while (true) {
+        chain_iter(k, pv, pv1, pvc); if (--k < 0) break;
+        chain_iter(k, pv1, pvc, pv); if (--k < 0) break;
+        chain_iter(k, pvc, pv, pv1); if (--k < 0) break;
+      }
     }
-    __syncthreads();
+    // the chain's per-lane slope / bias sums, through the wave: bias: the four lane groups of a column (four rows each); slope:
+    // the whole wave; red: [0] layer 0, [1] the shared hidden layer (all applications), per wave
+    {
+      float c0_ = cs_0, ch_ = cs_h, s0_ = ss_0, sh_ = ss_h;
+      c0_ += __shfl_xor(c0_, 16, 64); ch_ += __shfl_xor(ch_, 16, 64);
+      c0_ += __shfl_xor(c0_, 32, 64); ch_ += __shfl_xor(ch_, 32, 64);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { s0_ += __shfl_down(s0_, off, 64); sh_ += __shfl_down(sh_, off, 64); }
+      if (ct < NW && lq == 0) { bsum[(2 * 3 + pass) * 64 + col] = c0_; bsum[(1 * 3 + pass) * 64 + col] = ch_; }
+      if (lane == 0) { red[0 * 12 + wave] = ct < NW ? s0_ : 0.f; red[1 * 12 + wave] = ct < NW ? sh_ : 0.f; }
+    }
+    lds_barrier();
+    SK_STAMP(4);
     // ---- M[n < W][i < T] = sum over the group's users of D3[u][n] * temb[t_u][i], into the trailing columns of the layer-0 slab
     {
       const int TT = a.TPs / 16;
@@ -477,12 +583,14 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
                              : (c < a.WPs ? (kind == 1 ? a.dbHs : a.db0s) + (size_t)s * a.WPs + c : nullptr);
       if (dst && (kind != 1 || a.H >= 1)) *dst = first ? t : *dst + t;
     }
-    if (tid <= a.H) {
+    if (tid <= a.H) {   // application slots of alpha_part: [0] layer 0, [1] the hidden layer's total, [2 ..] nothing
       float sum = 0.f;
-      for (int w = 0; w < NWAVES; ++w) sum += red[tid * 12 + w];
+      if (tid < 2)
+        for (int w = 0; w < NWAVES; ++w) sum += red[tid * 12 + w];
       float* dst = a.alpha_part + (size_t)tid * a.alpha_part_stride + s;
-      *dst = first ? sum : *dst + sum;
+      if (first) *dst = sum; else *dst += sum;
     }
+    SK_STAMP(5);
   }
 }
 

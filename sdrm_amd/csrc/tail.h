@@ -46,7 +46,7 @@ struct TailJob {
   int64_t flat_off;             // TJ_SNAP: source = p + flat_off + r * flat_ld + c
   const float* src; size_t slab_stride; int src_ld, nslabs;   // MAT: src[s * slab_stride + r * src_ld + c]; VEC: src[s * slab_stride + i * src_ld]
   int inner;                    // SCALAR: sum of src[k * slab_stride + q], k < nslabs, q < inner
-  int lanes;                    // MAT: lanes per group of four columns: 4 (8 x 32 sub-tile per work-group) or 1 (32 x 32)
+  int lanes;                    // MAT: lanes per group of four columns: 4 (16 x 16 sub-tile per work-group), 2 (16 x 32) or 1 (32 x 32)
   int nblocks;                  // work-groups of this job
   float* red; int red_ld;       // MAT: non-null: the sums go to red[r * red_ld + c] and nothing else happens (M); SNAP: destination, row stride
   float* dst; float* dstT; float* dstF; float* dstFT;   // compute copies (any may be null): padded [r][c], transposed [c][r], fragment-packed
@@ -64,7 +64,9 @@ struct TailArgs {
   float* Mred; float* snap;
   float step_size, bc2_sqrt, b1, b2, eps, wd;
   int update;
+  unsigned long long* stamps;   // diagnostic runs only (SDRM_TAIL_STAMPS): 8 slots per work-group of k_tail
 };
+#define TSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[8 * (size_t)blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // Adam on an element whose state was loaded up front: g -> flat gradient, (w, m, v) -> p, m, v; returns the (new) value
 __device__ __forceinline__ float tail_apply_pre(const TailArgs& a, int64_t fi, float g, float w, float m, float v) {
@@ -77,16 +79,17 @@ __device__ __forceinline__ float tail_apply_pre(const TailArgs& a, int64_t fi, f
   return w;
 }
 
-// slabs [kb, ke) of the float4 at p + s * stride: up to sixteen loads in flight, summed in slab order (two chains: even, odd)
+// slabs [kb, ke) of the float4 at p + s * stride: up to BATCH loads in flight, summed in slab order (two chains: even, odd)
+template <int BATCH>
 __device__ __forceinline__ float4 slab_sum4(const float* __restrict__ p, size_t stride, int kb, int ke) {
   float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-  for (int k = kb; k < ke; k += 16) {
-    float4 vv[16];
+  for (int k = kb; k < ke; k += BATCH) {
+    float4 vv[BATCH];
 #pragma unroll
-    for (int u = 0; u < 16; ++u)
+    for (int u = 0; u < BATCH; ++u)
       vv[u] = (k + u < ke) ? *reinterpret_cast<const float4*>(p + (size_t)(k + u) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 16; u += 2) {
+    for (int u = 0; u < BATCH; u += 2) {
       a0.x += vv[u].x; a0.y += vv[u].y; a0.z += vv[u].z; a0.w += vv[u].w;
       a1.x += vv[u + 1].x; a1.y += vv[u + 1].y; a1.z += vv[u + 1].z; a1.w += vv[u + 1].w;
     }
@@ -111,19 +114,22 @@ __device__ __forceinline__ float quad_total(float v) {
   return v;
 }
 
-// One sub-tile of a weight matrix.  LANES = 4 (more than eight slabs): 8 rows x 32 columns, thread -> (row, column quad, part):
-// the four lanes of a column quad sum a quarter of the slabs each (at most sixteen 16-byte loads in flight per lane), the parts
-// meet through the wave in a fixed order, every lane then owns one element.  LANES = 1: 32 x 32, thread -> (row, column quad),
-// four elements each.
-template <int LANES>
+// One sub-tile of a weight matrix, thread -> (row, column quad, part): the LANES lanes of a column quad sum 1 / LANES of the slabs
+// each (at most BATCH 16-byte loads in flight per lane), the parts meet through the wave in a fixed order, every lane then owns
+// 4 / LANES of the quad's elements.  LANES = 4: 16 rows x 16 columns per work-group (more than 32 slabs); 2: 16 x 32 (a row of
+// the sub-tile is a whole 128-byte line of every slab: 64-byte pieces ran the slab read at 2.7 TB/s); 1: 32 x 32 (at most eight
+// slabs).  The compute copies are written out of an LDS image of the updated tile, each in the order that makes ITS addresses
+// consecutive: a 16 x 16 block is one contiguous 1 KiB piece of a fragment-packed copy (wfrag_index: [k / 16][n / 16]
+// [(k / 4) % 4][n % 16][k % 4]), 64-byte runs or more of the padded and the transposed copies.
+template <int LANES, int BATCH>
 __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, int bid, float* tsh) {
-  constexpr int TR = LANES == 4 ? 8 : 32, NE = LANES == 4 ? 1 : 4;
+  constexpr int TSR = LANES == 1 ? 32 : 16, TSC = LANES == 4 ? 16 : 32, QPR = TSC / 4, NE = 4 / LANES, NBC = TSC / 16;
   const int tid = threadIdx.x;
-  float (*tile)[33] = reinterpret_cast<float (*)[33]>(tsh);   // [TR][33]
-  const int tc = (jb.cols + 31) >> 5;
-  const int r0 = (bid / tc) * TR, c0 = (bid % tc) * 32;
+  float (*tile)[33] = reinterpret_cast<float (*)[33]>(tsh);   // [TSR][33]
+  const int tc = (jb.cols + TSC - 1) / TSC;
+  const int r0 = (bid / tc) * TSR, c0 = (bid % tc) * TSC;
   const int pos = tid / LANES, part = tid % LANES;
-  const int pr = pos >> 3, pq = pos & 7;
+  const int pr = pos / QPR, pq = pos % QPR;
   const int R = r0 + pr, Cq = c0 + 4 * pq;
   const bool rok = R < jb.rows;
   const bool reduce_only = jb.red != nullptr;
@@ -132,7 +138,7 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
   bool ok[NE];
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
-    const int C = Cq + (LANES == 4 ? part : e);
+    const int C = Cq + part * NE + e;
     ok[e] = rok && C < jb.cols;
     const int64_t fi = jb.flat_off + (int64_t)R * jb.flat_ld + C;
     w[e] = (ok[e] && !reduce_only) ? a.p[fi] : 0.f;
@@ -141,46 +147,59 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
   }
   const int kb = (jb.nslabs * part) / LANES, ke = (jb.nslabs * (part + 1)) / LANES;
   // (rows beyond the matrix: the loads go to row 0 and are not used - a tile may reach past the slab's padded rows)
-  float4 g4 = slab_sum4(jb.src + (size_t)(rok ? R : 0) * jb.src_ld + Cq, jb.slab_stride, kb, ke);
-  if (LANES == 4) { g4.x = quad_total(g4.x); g4.y = quad_total(g4.y); g4.z = quad_total(g4.z); g4.w = quad_total(g4.w); }
+  float4 g4 = slab_sum4<BATCH>(jb.src + (size_t)(rok ? R : 0) * jb.src_ld + Cq, jb.slab_stride, kb, ke);
+  if (LANES >= 2) { g4.x += __shfl_xor(g4.x, 1, 64); g4.y += __shfl_xor(g4.y, 1, 64); g4.z += __shfl_xor(g4.z, 1, 64); g4.w += __shfl_xor(g4.w, 1, 64); }
+  if (LANES == 4) { g4.x += __shfl_xor(g4.x, 2, 64); g4.y += __shfl_xor(g4.y, 2, 64); g4.z += __shfl_xor(g4.z, 2, 64); g4.w += __shfl_xor(g4.w, 2, 64); }
   const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+  TSTAMP(1);
   if (reduce_only) {
 #pragma unroll
     for (int e = 0; e < NE; ++e)
-      if (ok[e]) jb.red[(size_t)R * jb.red_ld + Cq + (LANES == 4 ? part : e)] = gv[LANES == 4 ? part : e];
+      if (ok[e]) jb.red[(size_t)R * jb.red_ld + Cq + part * NE + e] = gv[part * NE + e];
     return;
   }
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int ce = LANES == 4 ? part : e;
-    if (ok[e]) w[e] = tail_apply_pre(a, jb.flat_off + (int64_t)R * jb.flat_ld + Cq + ce, gv[ce], w[e], m[e], v[e]);
-  }
+  for (int e = 0; e < NE; ++e)
+    if (ok[e]) w[e] = tail_apply_pre(a, jb.flat_off + (int64_t)R * jb.flat_ld + Cq + part * NE + e, gv[part * NE + e], w[e], m[e], v[e]);
+  TSTAMP(2);
   if (!a.update) return;
-  // compute copies: only the entries of real elements are written (their padding stays as sdrm_create left it)
+  // the padded copy: a thread's quad (LANES = 1) or the lanes of the quad together are 16 consecutive bytes, a row of the tile 64 / 128
+  if (jb.dst) {
+    if (LANES == 1 && ok[3]) *reinterpret_cast<float4*>(jb.dst + (size_t)R * jb.dst_ld + Cq) = make_float4(w[0], w[1], w[2], w[3]);
+    else {
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int C = Cq + (LANES == 4 ? part : e);
-    if (ok[e]) {
-      if (jb.dst) jb.dst[(size_t)R * jb.dst_ld + C] = w[e];
-      if (jb.dstF) jb.dstF[wfrag_index(R, C, jb.fnct, jb.fklast)] = w[e];
+      for (int e = 0; e < NE; ++e)
+        if (ok[e]) jb.dst[(size_t)R * jb.dst_ld + Cq + part * NE + e] = w[e];
     }
   }
-  if (jb.dstT == nullptr && jb.dstFT == nullptr) return;
+  if (jb.dstT == nullptr && jb.dstF == nullptr && jb.dstFT == nullptr) return;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) tile[pr][4 * pq + (LANES == 4 ? part : e)] = w[e];
-  __syncthreads();
-  // transposed: thread -> (column of the tile, row): the rows of a column are consecutive addresses of the transposed copies
-  for (int f = tid; f < TR * 32; f += TAIL_THREADS) {
-    const int cc = f / TR, rr = f - cc * TR;
-    const int c = c0 + cc, r = r0 + rr;
-    if (c < jb.cols && r < jb.rows) {
-      const float t1 = tile[rr][cc];
-      if (jb.dstT) jb.dstT[(size_t)c * jb.dstT_ld + r] = t1;
-      if (jb.dstFT) jb.dstFT[wfrag_index(c, r, jb.fnct, jb.fklastT)] = t1;
+  for (int e = 0; e < NE; ++e) tile[pr][4 * pq + part * NE + e] = w[e];
+  lds_barrier();   // (not __syncthreads: that would wait for the p / m / v / g stores above)
+  TSTAMP(3);
+  // the other copies out of the LDS image (only the entries of real elements: their padding stays as sdrm_create left it)
+  for (int f = tid; f < TSR * TSC; f += TAIL_THREADS) {
+    if (jb.dstT) {   // [c][r]: consecutive threads -> consecutive rows of one column
+      const int cc = f / TSR, rr = f - cc * TSR;
+      if (c0 + cc < jb.cols && r0 + rr < jb.rows) jb.dstT[(size_t)(c0 + cc) * jb.dstT_ld + r0 + rr] = tile[rr][cc];
+    }
+    // fragment-packed: 16 x 16 block sb of the tile; inside it thread order (k group, n, k % 4) = the copy's address order
+    const int sb = f >> 8, e = f & 3, nn = (f >> 2) & 15, kg = (f >> 6) & 3;
+    const int sr = sb / NBC, sc = sb % NBC;
+    if (jb.dstF) {   // element (n = row, k = column)
+      const int rr = 16 * sr + nn, cc = 16 * sc + 4 * kg + e;
+      if (r0 + rr < jb.rows && c0 + cc < jb.cols) jb.dstF[wfrag_index(r0 + rr, c0 + cc, jb.fnct, jb.fklast)] = tile[rr][cc];
+    }
+    if (jb.dstFT) {  // element (n = column, k = row)
+      const int cc = 16 * sc + nn, rr = 16 * sr + 4 * kg + e;
+      if (r0 + rr < jb.rows && c0 + cc < jb.cols) jb.dstFT[wfrag_index(c0 + cc, r0 + rr, jb.fnct, jb.fklastT)] = tile[rr][cc];
     }
   }
 }
 
+// BATCH: 16-byte slab loads a lane keeps in flight: 8 when no lane of the launch has more than eight slabs to sum (the host
+// checks): the kernel then fits 64 registers and eight work-groups share a CU - at ML-1M all 1600 are resident at once
+template <int BATCH>
 __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
   __shared__ __attribute__((aligned(16))) float tsh[32 * 33];
   const int tid = threadIdx.x;
@@ -190,10 +209,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
     if (q < a.n && (int)blockIdx.x >= a.start[q]) k = q;
   const TailJob& jb = a.j[k];
   const int bid = (int)blockIdx.x - a.start[k];
+  TSTAMP(0);
+  if (a.stamps && tid == 0) { a.stamps[8 * (size_t)blockIdx.x + 6] = jb.kind; a.stamps[8 * (size_t)blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime(); }
 
   if (jb.kind == TJ_MAT) {
-    if (jb.lanes == 4) tail_mat<4>(a, jb, bid, tsh);
-    else tail_mat<1>(a, jb, bid, tsh);
+    if (jb.lanes == 4) tail_mat<4, BATCH>(a, jb, bid, tsh);
+    else if (jb.lanes == 2) tail_mat<2, BATCH>(a, jb, bid, tsh);
+    else tail_mat<1, BATCH>(a, jb, bid, tsh);
+    TSTAMP(4);
     return;
   }
 
@@ -212,35 +235,37 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
   }
 
   if (jb.kind == TJ_SNAP) {   // the pre-update snapshot of a parameter block [rows][cols] (read by the second launch)
-    const int64_t total = (int64_t)jb.rows * jb.cols;
-    const int64_t i0 = (int64_t)bid * (TAIL_THREADS * 8) + tid;
+    // a work-group takes 2048 consecutive elements of one row (the host cuts rows into such pieces): no index division here -
+    // an emulated 64-bit division per element was most of this job
+    const int ppr = (jb.cols + TAIL_THREADS * 8 - 1) / (TAIL_THREADS * 8);   // pieces per row
+    const int r = bid / ppr, c0 = (bid - r * ppr) * (TAIL_THREADS * 8);
+    const float* src = a.p + jb.flat_off + (int64_t)r * jb.flat_ld + c0;
+    float* dst = jb.red + (int64_t)r * jb.red_ld + c0;
+    const int n = min(TAIL_THREADS * 8, jb.cols - c0);
     float vv[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t i = i0 + u * TAIL_THREADS;
-      vv[u] = i < total ? a.p[jb.flat_off + (i / jb.cols) * jb.flat_ld + (i % jb.cols)] : 0.f;
-    }
+    for (int u = 0; u < 8; ++u) vv[u] = tid + u * TAIL_THREADS < n ? src[tid + u * TAIL_THREADS] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t i = i0 + u * TAIL_THREADS;
-      if (i < total) jb.red[(i / jb.cols) * jb.red_ld + (i % jb.cols)] = vv[u];
-    }
+    for (int u = 0; u < 8; ++u)
+      if (tid + u * TAIL_THREADS < n) dst[tid + u * TAIL_THREADS] = vv[u];
     return;
   }
 
   // ---- TJ_SCALAR: thousands of partials (one per dgrad work-group and application): every thread takes up to 16, all in flight
   const float w0 = a.p[jb.flat_off], m0 = a.update ? a.m[jb.flat_off] : 0.f, v0 = a.update ? a.v[jb.flat_off] : 0.f;
   float s = 0.f;
-  const int total = jb.nslabs * jb.inner;
-  for (int i0 = 0; i0 < total; i0 += TAIL_THREADS * 16) {
-    float vv[16];
+  for (int k = 0; k < jb.nslabs; ++k) {   // application k: `inner` partials, sixteen per thread in flight
+    const float* src = jb.src + (size_t)k * jb.slab_stride;
+    for (int i0 = 0; i0 < jb.inner; i0 += TAIL_THREADS * 16) {
+      float vv[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int i = i0 + u * TAIL_THREADS + tid;
-      vv[u] = i < total ? jb.src[(size_t)(i / jb.inner) * jb.slab_stride + (i % jb.inner)] : 0.f;
+      for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u * TAIL_THREADS + tid;
+        vv[u] = i < jb.inner ? src[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += vv[u];
     }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s += vv[u];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -250,14 +275,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
 }
 
 // ---- second launch: the embedding path.  Work-groups [0, nA): 8 rows x 32 columns of W0e; [nA, nA + nB): 16 x 16 tiles of
-// emb_layer.weight; the last one: emb_layer.bias.
+// emb_layer.weight; then 16 entries of emb_layer.bias each.
 constexpr int TE_RB = 8, TE_JT = 32;     // W0e work-groups: rows, columns
 constexpr int TE_WT = 16, TE_WC = 128;   // emb_layer.weight work-groups: tile edge, rows of the contraction per chunk
 __host__ __device__ inline int tail_emb_blocks_a(int W, int T) { return ((W + TE_RB - 1) / TE_RB) * ((T + TE_JT - 1) / TE_JT); }
 __host__ __device__ inline int tail_emb_blocks_b(int T) { return ((T + TE_WT - 1) / TE_WT) * ((T + TE_WT - 1) / TE_WT); }
+__host__ __device__ inline int tail_emb_blocks_c(int T) { return (T + 15) / 16; }
 __host__ __device__ inline size_t tail_emb_lds_floats(int T, int TP) {
   const size_t a_ = (size_t)TE_JT * (T + 1) + (size_t)TE_RB * TP + TE_RB + TE_JT;
-  const size_t b_ = (size_t)2 * 2 * TE_WC * (TE_WT + 1);
+  const size_t b_ = (size_t)2 * 2 * TE_WC * (TE_WT + 2);
   return (a_ > b_ ? a_ : b_) + 8;
 }
 
@@ -289,19 +315,26 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
     if (tid < nmq && w0 + tid / (TP / 4) < a.W) mq = *reinterpret_cast<const float4*>(a.Mred + (size_t)(w0 + tid / (TP / 4)) * TP + 4 * (tid % (TP / 4)));
     const float dbv = (tid < TE_RB && w0 + tid < a.W) ? a.g[a.off_b0 + w0 + tid] : 0.f;
     const float bev = (tid >= 32 && tid < 64 && j0 + tid - 32 < T) ? snapbe[j0 + tid - 32] : 0.f;
-    const int nwe = TE_JT * T;
-    for (int f0 = 0; f0 < nwe; f0 += 16 * 256) {
-      float vv[16];
+    // We rows j0 .. j0 + 31: wave w takes rows w, w + 4, .. (eight of them), its lanes the columns i = lane, lane + 64, ..
+    // (coalesced, and no index division: an emulated division per element was most of this work-group's time)
+    {
+      const int wv = tid >> 6, ln = tid & 63;
+      for (int i0 = 0; i0 < T; i0 += 128) {
+        float vv[8][2];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int f = f0 + u * 256 + tid;
-        const int jr = f / T, i = f - jr * T;
-        vv[u] = (f < nwe && j0 + jr < T) ? snapWe[(size_t)(j0 + jr) * T + i] : 0.f;
-      }
+        for (int rr = 0; rr < 8; ++rr)
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int f = f0 + u * 256 + tid;
-        if (f < nwe) WeS[(f / T) * (T + 1) + (f % T)] = vv[u];
+          for (int h = 0; h < 2; ++h) {
+            const int jr = wv + 4 * rr, i = i0 + ln + 64 * h;
+            vv[rr][h] = (j0 + jr < T && i < T) ? snapWe[(size_t)(j0 + jr) * T + i] : 0.f;
+          }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int jr = wv + 4 * rr, i = i0 + ln + 64 * h;
+            if (i < T) WeS[jr * (T + 1) + i] = vv[rr][h];
+          }
       }
     }
     if (tid < nmq) *reinterpret_cast<float4*>(Ms + 4 * tid) = mq;
@@ -324,15 +357,17 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
   }
   bid -= nA;
   if (bid < nB) {
-    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: a 16 x 16 tile, thread -> (j, i); the contraction in chunks of 128
-    // rows through LDS, the next chunk's loads in flight while this one is multiplied
+    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: a 16 x 16 tile per work-group; the contraction in chunks of 128 rows
+    // through LDS (the next chunk's loads in flight while this one is multiplied).  Wave v takes rows v, v + 4, .. of a chunk for
+    // ALL 256 outputs, 2 x 2 of them per lane (two 8-byte LDS reads per four multiply-adds); the four waves' sums meet in LDS.
     const int nt = (T + TE_WT - 1) / TE_WT;
     const int j0 = (bid / nt) * TE_WT, i0 = (bid % nt) * TE_WT;
-    const int jj = tid >> 4, ii = tid & 15;
+    const int jj = tid >> 4, ii = tid & 15;                 // this thread's OUTPUT (after the waves' sums have met)
     const bool own = j0 + jj < T && i0 + ii < T;
     const int64_t fi = a.off_we + (int64_t)(own ? j0 + jj : 0) * T + (own ? i0 + ii : 0);
     const float ow = a.p[fi], om = a.update ? a.m[fi] : 0.f, ov = a.update ? a.v[fi] : 0.f;
     constexpr int PER = TE_WC * TE_WT / 256;   // 8 floats of each operand per thread and chunk: (row f / 16, column f % 16)
+    constexpr int LDT = TE_WT + 2;             // LDS row stride: even (8-byte reads), 18 floats
     float xa[PER], xb[PER];
     auto load = [&](int wc0) __attribute__((always_inline)) {
 #pragma unroll
@@ -342,45 +377,70 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
         xb[u] = (wr_ < a.W && i0 + cc < T) ? a.Mred[(size_t)wr_ * TP + i0 + cc] : 0.f;
       }
     };
-    float acc0 = 0.f, acc1 = 0.f;
+    const int wv = tid >> 6, ln = tid & 63, jq = ln >> 3, iq = ln & 7;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     load(0);
     int buf = 0;
     for (int wc0 = 0; wc0 < a.W; wc0 += TE_WC, buf ^= 1) {
-      float* As = esh + buf * 2 * TE_WC * (TE_WT + 1);
-      float* Bs = As + TE_WC * (TE_WT + 1);
+      float* As = esh + buf * 2 * TE_WC * LDT;
+      float* Bs = As + TE_WC * LDT;
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = u * 256 + tid;
-        As[(f >> 4) * (TE_WT + 1) + (f & 15)] = xa[u];
-        Bs[(f >> 4) * (TE_WT + 1) + (f & 15)] = xb[u];
+        As[(f >> 4) * LDT + (f & 15)] = xa[u];
+        Bs[(f >> 4) * LDT + (f & 15)] = xb[u];
       }
       if (wc0 + TE_WC < a.W) load(wc0 + TE_WC);
-      __syncthreads();   // (two LDS buffers: the chunk written now was last read two iterations ago, behind the barrier in between)
+      lds_barrier();     // (LDS only: the next chunk's loads stay in flight; two LDS buffers: the chunk written now was last read two
+                         // iterations ago, behind the barrier in between)
 #pragma unroll 8
-      for (int q = 0; q < TE_WC; q += 2) {
-        acc0 = fmaf(As[q * (TE_WT + 1) + jj], Bs[q * (TE_WT + 1) + ii], acc0);
-        acc1 = fmaf(As[(q + 1) * (TE_WT + 1) + jj], Bs[(q + 1) * (TE_WT + 1) + ii], acc1);
+      for (int q = wv; q < TE_WC; q += 4) {
+        const float2 av = *reinterpret_cast<const float2*>(As + q * LDT + 2 * jq);
+        const float2 bv = *reinterpret_cast<const float2*>(Bs + q * LDT + 2 * iq);
+        acc[0][0] = fmaf(av.x, bv.x, acc[0][0]); acc[0][1] = fmaf(av.x, bv.y, acc[0][1]);
+        acc[1][0] = fmaf(av.y, bv.x, acc[1][0]); acc[1][1] = fmaf(av.y, bv.y, acc[1][1]);
       }
     }
-    if (own) tail_apply_pre(a, fi, acc0 + acc1, ow, om, ov);
+    lds_barrier();   // every wave is done with the operand buffers: they become the waves' partial sums [4][16][16]
+    float* red = esh;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y) red[wv * 256 + (2 * jq + x) * 16 + 2 * iq + y] = acc[x][y];
+    lds_barrier();
+    if (own) tail_apply_pre(a, fi, ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid], ow, om, ov);
     return;
   }
-  // d emb_layer.bias[j] = sum_w W0e[w][j] * db0[w]: thread -> j (and j + 256 ..), sixteen rows of the contraction in flight
-  for (int j = tid; j < T; j += 256) {
-    const int64_t fi = a.off_be + j;
+  // d emb_layer.bias[j] = sum_w W0e[w][j] * db0[w]: 16 columns per work-group, thread -> (column tid % 16, slice tid / 16 of the
+  // rows: w = slice, slice + 16, ..): up to 32 rows per thread in flight at once (a single thread per column walking all W rows
+  // in batches was a chain of W / 16 dependent round trips: 11 us at W = 340, 25 at 830 - the whole launch)
+  bid -= nB;
+  {
+    const int jj = tid & 15, sl = tid >> 4, j = bid * 16 + jj;
+    const bool jok = j < T;
+    const int64_t fi = a.off_be + (jok ? j : 0);
     const float ow = a.p[fi], om = a.update ? a.m[fi] : 0.f, ov = a.update ? a.v[fi] : 0.f;
     float s0 = 0.f, s1 = 0.f;
-    for (int w0 = 0; w0 < a.W; w0 += 16) {
-      float xv[16], dv[16];
+    for (int w0 = sl; w0 < a.W; w0 += 16 * 32) {
+      float xv[32], dv[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        xv[u] = w0 + u < a.W ? snapW0e[(size_t)(w0 + u) * T + j] : 0.f;
-        dv[u] = w0 + u < a.W ? a.g[a.off_b0 + w0 + u] : 0.f;
+      for (int u = 0; u < 32; ++u) {
+        const int w = w0 + 16 * u;
+        xv[u] = (w < a.W && jok) ? snapW0e[(size_t)w * T + j] : 0.f;
+        dv[u] = w < a.W ? a.g[a.off_b0 + w] : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u += 2) { s0 = fmaf(xv[u], dv[u], s0); s1 = fmaf(xv[u + 1], dv[u + 1], s1); }
+      for (int u = 0; u < 32; u += 2) { s0 = fmaf(xv[u], dv[u], s0); s1 = fmaf(xv[u + 1], dv[u + 1], s1); }
     }
-    tail_apply_pre(a, fi, s0 + s1, ow, om, ov);
+    float* red = esh;   // [16 slices][16 columns]
+    red[tid] = s0 + s1;
+    lds_barrier();
+    if (tid < 16 && jok) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[16 * q + tid];
+      tail_apply_pre(a, fi, s, ow, om, ov);
+    }
   }
 }
 

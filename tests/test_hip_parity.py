@@ -313,9 +313,9 @@ def test_train_step_vs_oracle(engine_cls, dims, train_path):
 
 @pytest.mark.parametrize("dims", [(40, 40, 93, 5, 850), (24, 56, 11, 3, 37), (64, 17, 8, 0, 5), (33, 48, 20, 1, 129)])
 def test_narrow_net_train_paths_agree(engine_cls, dims):
-    """Nets with widths <= 64 run their train forward and dgrad chain in the fused kernels of csrc/skinny_train.h
-    (EXPLICIT and PHILOX staging); the general per-layer GEMM path must give the same step: P/S/Q, loss, every
-    gradient tensor, the parameters after Adam.  Same arithmetic, different summation order: 2e-5 normwise."""
+    """Nets with widths <= 64 run their train forward and their whole backward (dgrad chain + every weight gradient) in the two
+    kernels of csrc/skinny_step.h (EXPLICIT and PHILOX staging); the general per-layer GEMM path must give the same step: P/S/Q,
+    loss, every gradient tensor, the parameters after Adam.  Same arithmetic, different summation order: 2e-5 normwise."""
     L, W, T, H, B = dims
     init = synth.flatten_params(synth.init_params(L, W, T, H, seed=16), H)
     x0 = synth.synth_latents(B, L, seed=17)
@@ -342,6 +342,37 @@ def test_narrow_net_train_paths_agree(engine_cls, dims):
         for (n, a), (_, b) in zip(per_tensor(g1, dims[:4]), per_tensor(g0, dims[:4])):
             assert rel_l2(a, b) <= 2e-5 and rel_max(a, b) <= 2e-5, (mode, n, rel_l2(a, b), rel_max(a, b))
         assert rel_l2(w1, w0) <= TOL, mode   # Adam's first step is lr*sign(g): a sign flip of a ~0 gradient moves a weight by 2*lr
+
+
+@pytest.mark.parametrize("dims", [(10, 10, 5, 1, 25), (20, 40, 9, 2, 33), (60, 50, 7, 0, 40), (40, 40, 93, 5, 107), (16, 16, 130, 1, 1100)])
+def test_narrow_net_steps_are_reproducible(engine_cls, dims):
+    """Every column-tile count of the narrow nets' kernels (1..4 tiles: work-groups of 3, 6, 9, 12 waves), more user groups than
+    slab sets (B = 1100: 69 groups on 64 work-groups), an embedding wider than the one-round-trip path of the tail (T = 130): four
+    fused train steps run twice - and from a shifted, odd-aligned x0 - leave the same bits in the parameters (a fold over the loss
+    partials that read a wave's slot no wave had written went unnoticed by the parity tests of round 4's first version: its steps
+    differed from run to run in the sixth digit), and agree with the general per-layer path to fp32 summation order."""
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H)
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)).cuda()
+
+    def run(skinny=True, off=0):
+        e = engine_cls(L, W, T, H, B).debug_set(skinny=skinny)
+        e.set_params(init)
+        big = torch.zeros(B * L + off + 8, device="cuda")
+        big[off:off + B * L] = x0.reshape(-1)
+        xv = big[off:off + B * L].view(B, L)
+        losses = [float(e.train_step(xv, 1e-3, seed=5, step=k).cpu()) for k in range(4)]
+        p = e.get_params().cpu().numpy().copy()
+        e.close()
+        return p, losses
+
+    a, la = run()
+    b, lb = run()
+    c, lc = run(off=1)
+    d, ld = run(skinny=False)
+    assert np.array_equal(a, b) and la == lb
+    assert np.array_equal(a, c) and la == lc
+    assert rel_l2(a, d) <= TOL and np.allclose(la, ld, rtol=1e-4)
 
 
 @pytest.mark.parametrize("path", [-1, "row", "row-layers", "row-tiles"])
