@@ -84,6 +84,10 @@ int sdrm_get_schedule(const sdrm_engine* e, float* beta_host, float* alpha_host,
 /* ---- parameters / optimiser state (nn.Module.state_dict / torch.optim.Adam state) ------------ */
 int sdrm_set_params(sdrm_engine* e, const float* flat, void* stream);
 int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream);
+/* The live parameters in place: DEVICE pointer to the library's flat master vector [P] (what nn.Module.parameters() hands out in
+ * the reference, hyperparameter_search.py:53: views, not copies).  Valid until sdrm_destroy.  READ-ONLY for the caller: the
+ * kernels read padded / transposed / fragment-packed compute copies that only sdrm_set_params and the train step refresh. */
+const float* sdrm_params_ptr(const sdrm_engine* e);
 /* Gradient of the last backward, flat [P] (what autograd leaves in p.grad after :336).  If that backward was
  * given a caller buffer (`grad`), this reads from it: the buffer must still be alive. */
 int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream);
@@ -259,15 +263,6 @@ typedef struct sdrm_vae_decoder {
   int latent, hidden, n_items;
 } sdrm_vae_decoder;
 int sdrm_vae_decode(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, float* out, void* stream);
-/* Decode and equal-sparsity binarisation in one call (main.py:170-180: `sample_ddpm(...)` then `np.quantile(M.flatten(),
- * SPARSITY)` and `M >= threshold`): the first of the three radix-select sweeps over the [n, n_items] matrix is taken by the
- * output layer's epilogue while it writes the matrix, so the matrix is written once and swept three times instead of four.
- * raw_out [n, n_items] float32 (16-byte aligned) receives the decoded scores, or NULL to keep them in library scratch; out
- * (uint8 [n, n_items], 4-byte aligned, may be NULL) and threshold (device float, may be NULL) are as in sdrm_equal_sparsity,
- * and identical to what sdrm_equal_sparsity returns for the same matrix. */
-int sdrm_vae_decode_equal_sparsity(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, double q, float* raw_out,
-                                   uint8_t* out, float* threshold, void* stream);
-
 /* Recall@k and NDCG@k of a score matrix against held-out interactions (reference: utilities.py:116-171,
  * mask_training_examples + recall_at_k_batch + NDCG_binary_at_k_batch, as svd_benchmark.py:58-66 chains them).
  * scores [U, I] float32 row-major; held_* / train_* are CSR index arrays over the same U rows (int64 indptr [U+1],

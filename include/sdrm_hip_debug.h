@@ -69,6 +69,14 @@ int sdrm_debug_set_chains(sdrm_engine* e, int chains);
  * SDRM_AR_BUCKETS.  The result is the same bit for bit. */
 int sdrm_debug_set_gradient_buckets(sdrm_engine* e, int buckets);
 
+/* The on-device generator's draws as the staging kernels consume them (csrc/philox.h): for rows row0 .. row0 + rows - 1 and column
+ * quads 0 .. quads - 1, one Philox4x32-10 call keyed by (seed, step, purpose) each: normals [rows, 4 * quads] float32 (two
+ * Box-Muller pairs per call) and, when lowbits is not NULL, [rows, 4 * quads] uint8 holding bits 0..2 of the call's four words
+ * (the dropout keep bits of the three passes of a train step).  purpose: 1 = train step elements, 3 = sampling start noise,
+ * 4 | (i << 8) = reverse step i.  For the statistical tests of the generator (tests/test_philox_stats.py). */
+int sdrm_debug_philox_draws(sdrm_engine* e, uint64_t seed, uint32_t purpose, uint32_t step, int64_t row0, int rows, int quads,
+                            float* normals, uint8_t* lowbits, void* stream);
+
 /* The engine's ncclComm_t (NULL without one): lets a test hand a communicator made elsewhere to sdrm_allreduce_init. */
 void* sdrm_debug_comm_handle(const sdrm_engine* e);
 

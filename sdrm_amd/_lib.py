@@ -33,6 +33,7 @@ SIGNATURES = {
     "sdrm_get_schedule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdrm_set_params": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sdrm_get_params": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "sdrm_params_ptr": (c_void_p, [c_void_p]),
     "sdrm_get_grads": (c_int, [c_void_p, c_void_p, c_void_p]),
     "sdrm_get_adam_state": (c_int, [c_void_p, c_void_p, c_void_p, C.POINTER(c_int64), c_void_p]),
     "sdrm_set_adam_state": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
@@ -78,13 +79,12 @@ SIGNATURES = {
     "sdrm_build_info": (C.c_char_p, []),
     "sdrm_csr_rows_to_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "sdrm_vae_decode": (c_int, [c_void_p, C.POINTER(VaeDecoder), c_void_p, c_int, c_void_p, c_void_p]),
-    "sdrm_vae_decode_equal_sparsity": (c_int, [c_void_p, C.POINTER(VaeDecoder), c_void_p, c_int, C.c_double, c_void_p, c_void_p,
-                                               c_void_p, c_void_p]),
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),
     "sdrm_rank_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sdrm_source_hash": (C.c_char_p, []),
     # include/sdrm_hip_debug.h (test / tuning hooks; every setter acts on one handle)
+    "sdrm_debug_philox_draws": (c_int, [c_void_p, c_uint64, C.c_uint32, C.c_uint32, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "sdrm_debug_set_tile": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_nt32_rows": (c_int, [c_void_p, c_int, c_int]),
     "sdrm_debug_set_chains": (c_int, [c_void_p, c_int]),

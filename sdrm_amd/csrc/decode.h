@@ -8,9 +8,15 @@
 
 namespace sdrm {
 
-// dst[rowsP][colsP] (row-major, colsP a multiple of 4) = src[rows][cols] zero-padded
-__global__ __launch_bounds__(256) void k_pad2d(const float* __restrict__ src, int rows, int cols, float* __restrict__ dst,
-                                               int rowsP, int colsP) {
+// dst[rowsP][colsP] (row-major, colsP a multiple of 4) = src[rows][cols] zero-padded; the five operands of a decode (latents, two
+// weights, two biases) in ONE launch: segment = blockIdx.y (five launches of a few microseconds each were most of the decode's
+// time at the small shapes, where the engine's decode lost to the PyTorch module)
+struct PadSegs { const float* src[5]; float* dst[5]; int rows[5], cols[5], rowsP[5], colsP[5]; };
+__global__ __launch_bounds__(256) void k_pad2d(const PadSegs sg) {
+  const int k = blockIdx.y;
+  const float* __restrict__ src = sg.src[k];
+  float* __restrict__ dst = sg.dst[k];
+  const int rows = sg.rows[k], cols = sg.cols[k], rowsP = sg.rowsP[k], colsP = sg.colsP[k];
   const int qpr = colsP >> 2;
   const int64_t total = (int64_t)rowsP * qpr;
   const bool vec = (cols & 3) == 0 && ((uintptr_t)src & 15u) == 0;

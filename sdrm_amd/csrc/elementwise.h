@@ -759,6 +759,23 @@ __global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L,
   }
 }
 
+// Test hook (sdrm_debug_philox_draws): the generator's output exactly as the staging kernels consume it - one Philox call per
+// (row, column quad): four normals (two Box-Muller pairs) and the low bits of the four words (bit b of word j = keep bit of
+// pass b for column j in the train step).
+__global__ __launch_bounds__(256) void k_philox_draws(uint32_t seed_lo, uint32_t seed_hi, uint32_t purpose, uint32_t step, int64_t row0, int rows,
+                                                      int quads, float* __restrict__ normals, uint8_t* __restrict__ lowbits) {
+  const size_t total = (size_t)rows * quads;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / quads), q = (int)(i - (size_t)r * quads);
+    const U4 w = philox4x32_10((uint32_t)(row0 + r), (uint32_t)q, purpose, step, seed_lo, seed_hi);
+    float n[4];
+    box_muller(w.x, w.y, n[0], n[1]);
+    box_muller(w.z, w.w, n[2], n[3]);
+    *reinterpret_cast<float4*>(normals + 4 * i) = make_float4(n[0], n[1], n[2], n[3]);
+    if (lowbits) *reinterpret_cast<uint32_t*>(lowbits + 4 * i) = (w.x & 7u) | ((w.y & 7u) << 8) | ((w.z & 7u) << 16) | ((w.w & 7u) << 24);
+  }
+}
+
 // x <- (x - eps_hat * c1) / sqrt(alpha_i) + sqrt(beta_i) * z   (denoise_add_noise, :20-25)
 __global__ __launch_bounds__(256) void k_reverse_apply(float* x, const float* Y, int ldy, const float* z, int n, int L,
                                                        float c1, float sqrt_alpha, float sqrt_beta) {

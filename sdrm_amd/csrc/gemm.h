@@ -55,11 +55,9 @@ enum : int {
   EPI_BIAS_G = 7,        // C = acc + bias[n], bounds-checked into an unpadded caller buffer (VAE decode output layer)
   EPI_BIAS_ROWTAB = 9,   // C = acc + tab[t(row)][n]: layer 0 of the train step, whose bias + time-embedding term b0 + C0[t] is a
                          // row of the per-step table B0tab picked by the row's timestep (the stacked passes P, S, Q share t)
-  EPI_BIAS_PRELU = 10,   // C = prelu(acc + bias[n]; slopeE): the sampler's hidden layers store the ACTIVATION - nothing reads their
+  EPI_BIAS_PRELU = 10    // C = prelu(acc + bias[n]; slopeE): the sampler's hidden layers store the ACTIVATION - nothing reads their
                          // pre-activations again (no backward), and the next layer then loads its operand without the PReLU-on-load
                          // transform, which costs the 5429-row launches ~1.5 us each (12.7 us plain against 16 us with it)
-  EPI_BIAS_G_HIST = 8    // same, and the first radix-select histogram of the values written (sdrm_vae_decode_equal_sparsity:
-                         // the equal-sparsity threshold's first sweep over the [users, items] matrix rides on its producer)
 };
 
 constexpr int NTHREADS = 256;
@@ -124,8 +122,6 @@ struct GemmArgs {
   float* revX; float* revU; int rev_ldx, rev_s0, rev_n, rev_L, rev_step;
   float rev_c1, rev_sqrt_alpha, rev_sqrt_beta, rev_nd;
   uint32_t rev_seed_lo, rev_seed_hi, rev_call_id; int64_t rev_row0;
-  // EPI_BIAS_G_HIST: SelectState::hist[0][0] (2048 bins of the top 11 key bits), integer atomics
-  uint32_t* hist;
   // EPI_BIAS_ROWTAB: `bias` is the table [T+1][ldtab]; stacked row r (< 3 * trow_B) belongs to user r mod trow_B, whose timestep
   // is trow[user]; pad rows use t = 0
   const int* trow; int trow_B, ldtab;
@@ -652,14 +648,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   const float slopeE = (EPI == EPI_DPRELU) ? *p.slopeE : 0.f;
   const float slopeP = (EPI == EPI_BIAS_PRELU) ? *p.slopeE : 0.f;
   float* __restrict__ Cp = p.C;
-  // EPI_BIAS_G_HIST: the main loop is over (its last K-step ended in a barrier), so the operand stages become two copies
-  // of the 2048-bin digit histogram (lane parity picks the copy: halves the same-address serialisation on the hot bins)
-  uint32_t* hs = reinterpret_cast<uint32_t*>(smem);
-  if (EPI == EPI_BIAS_G_HIST) {
-    static_assert(EPI != EPI_BIAS_G_HIST || 2 * Cfg::STAGE >= 2 * SEL_BINS, "LDS too small for the histogram copies");
-    for (int j = tid; j < 2 * SEL_BINS; j += NTHREADS) hs[j] = 0u;
-    __syncthreads();
-  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -671,7 +659,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
       const int rbase = tm0 + 4 * lhi;
       float bias = 0.f;
       if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH || EPI == EPI_BIAS_TANH_G || EPI == EPI_TANH_REV || EPI == EPI_BIAS_G ||
-          EPI == EPI_BIAS_G_HIST || EPI == EPI_BIAS_PRELU)
+          EPI == EPI_BIAS_PRELU)
         bias = p.bias[col];
       if (EPI == EPI_BIAS || EPI == EPI_PLAIN) {
 #pragma unroll
@@ -728,16 +716,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         for (int r = 0; r < NR; ++r) bt[r] = p.bias[(size_t)tt[r] * p.ldtab + col];
 #pragma unroll
         for (int r = 0; r < NR; ++r) Cp[(size_t)(rbase + rowoff(r)) * p.ldc + col] = acc[a][b][r] + bt[r];
-      } else if (EPI == EPI_BIAS_G || EPI == EPI_BIAS_G_HIST) {
-        uint32_t* mine = hs + (lane & 1) * SEL_BINS;
+      } else if (EPI == EPI_BIAS_G) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const int row = rbase + rowoff(r);
-          if (row < p.rows_valid && col < p.cols_valid) {
-            const float v = acc[a][b][r] + bias;
-            Cp[(size_t)row * p.ldc + col] = v;
-            if (EPI == EPI_BIAS_G_HIST) atomicAdd(&mine[float_key(v) >> sel_shift(0)], 1u);
-          }
+          if (row < p.rows_valid && col < p.cols_valid) Cp[(size_t)row * p.ldc + col] = acc[a][b][r] + bias;
         }
       } else if (EPI == EPI_DPRELU) {
         const float* __restrict__ auxp = p.aux;
@@ -778,13 +761,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
 #endif
   }
 #endif
-  if (EPI == EPI_BIAS_G_HIST) {
-    __syncthreads();
-    for (int j = tid; j < SEL_BINS; j += NTHREADS) {
-      const uint32_t c = hs[j] + hs[SEL_BINS + j];
-      if (c) atomicAdd(&p.hist[j], c);
-    }
-  }
   if (EPI == EPI_DPRELU) {
     // block-wide sum of the slope-gradient partial -> one float per block (deterministic order)
 #pragma unroll

@@ -119,9 +119,9 @@ struct sdrm_engine {
   int bwd_S0 = 1, bwd_SH = 1, bwd_SO = 1, bwd_kc0 = 0, bwd_kcH = 0, bwd_kcO = 0, bwd_dgrad_blocks = 0;
   int bwd_hidden_apps = 0;           // slab sets of the shared hidden layer's weight gradient per K-slice: H (one per application), or 1 (already summed)
   int bwd_cfg_w = 0;                 // tile of the split-K launches, fixed by backward_chain for the whole backward
-  // grow-only scratch of sdrm_vae_decode (padded latents / weights / hidden activations; the raw matrix when the caller keeps none)
-  float* dec_buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t dec_cap[7] = {0, 0, 0, 0, 0, 0, 0};
+  // grow-only scratch of sdrm_vae_decode (padded latents / weights / hidden activations)
+  float* dec_buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t dec_cap[6] = {0, 0, 0, 0, 0, 0};
   Exchange xch;                      // RCCL communicator of the user-sharded step (sdrm_comm_init_rank / sdrm_allreduce_init)
   mutable int64_t n_launches = 0;    // kernel launches issued through this handle since sdrm_create
   // The sampler's own copy of everything it reads of the net (padded weights, biases, the folded bias table b0 + C0[i], the two
@@ -927,6 +927,16 @@ int sdrm_debug_plan_wgrad(int rows, int n_out, int k_in, int* slices, int* rows_
   return SDRM_OK;
 }
 
+int sdrm_debug_philox_draws(sdrm_engine* e, uint64_t seed, uint32_t purpose, uint32_t step, int64_t row0, int rows, int quads,
+                            float* normals, uint8_t* lowbits, void* stream) {
+  if (!e || !normals || rows < 1 || quads < 1) return fail(e, SDRM_ERR_ARG, "sdrm_debug_philox_draws: bad argument");
+  const size_t total = (size_t)rows * quads;
+  SDRM_LAUNCH(e, k_philox_draws, dim3((unsigned)std::min<size_t>(8192, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+              (uint32_t)seed, (uint32_t)(seed >> 32), purpose, step, row0, rows, quads, normals, lowbits);
+  HIP_TRY(e, hipGetLastError());
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode) {
   if (!e) return SDRM_ERR_ARG;
   e->tune.fuse_rev = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
@@ -1138,6 +1148,8 @@ int sdrm_get_params(const sdrm_engine* e, float* flat, void* stream) {
   HIP_TRY(me, hipMemcpyAsync(flat, e->p, e->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return SDRM_OK;
 }
+
+const float* sdrm_params_ptr(const sdrm_engine* e) { return e ? e->p : nullptr; }
 
 int sdrm_get_grads(const sdrm_engine* e, float* flat, void* stream) {
   if (!e || !flat) return SDRM_ERR_ARG;
@@ -2110,17 +2122,13 @@ void quantile_ranks(int64_t n, double q, int64_t& r0, int64_t& r1, float& gamma)
   }
 }
 
-// The select sweeps from `first_pass` on (0: all three; 1: the first histogram was accumulated by the producer of x - the
-// decode GEMM's epilogue - after a k_select_init for the same ranks), then the threshold and the binarise sweep.
-int select_and_binarize(sdrm_engine* e, const float* x, int64_t n, float gamma, int first_pass, uint8_t* out, float* threshold,
-                        hipStream_t st) {
+// The three select sweeps, then the threshold and the binarise sweep.
+int select_and_binarize(sdrm_engine* e, const float* x, int64_t n, float gamma, uint8_t* out, float* threshold, hipStream_t st) {
   const int blocks = (int)std::min<int64_t>(2048, (n / 4 + 255) / 256 + 1);
   for (int pass = 0; pass < SEL_PASSES; ++pass) {
-    if (pass >= first_pass) {
-      if (pass == 0) SDRM_LAUNCH(e, (k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
-      else SDRM_LAUNCH(e, (k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
-      HIP_TRY(e, hipGetLastError());
-    }
+    if (pass == 0) SDRM_LAUNCH(e, (k_select_hist<4>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    else SDRM_LAUNCH(e, (k_select_hist<1>), dim3(blocks), dim3(256), 0, st, x, n, e->sel, pass);
+    HIP_TRY(e, hipGetLastError());
     SDRM_LAUNCH(e, k_select_pick, dim3(1), dim3(256), 0, st, e->sel, pass, gamma);
     HIP_TRY(e, hipGetLastError());
   }
@@ -2140,9 +2148,8 @@ int dec_grow(sdrm_engine* e, int slot, size_t n) {
   return SDRM_OK;
 }
 
-// decoder(z) = Linear(hidden, items)(tanh(Linear(latent, hidden)(z)))   (train_SDRM.py:212-214, :252-254); with_hist: the
-// output layer's epilogue also accumulates the first select histogram of the values it writes into e->sel
-int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, int n, float* out, bool with_hist, hipStream_t st) {
+// decoder(z) = Linear(hidden, items)(tanh(Linear(latent, hidden)(z)))   (train_SDRM.py:212-214, :252-254): one staging launch, two GEMMs
+int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, int n, float* out, hipStream_t st) {
   const int Lp = round_up(d->latent, 32), Hp = round_up(d->hidden, 32), Ip = round_up(d->n_items, 32);
   const int MP = round_up(n, 128), Hr = round_up(Hp, 128), Ir = round_up(Ip, 128);
   enum { Z = 0, W1, B1, HID, W2, B2 };
@@ -2150,16 +2157,23 @@ int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, i
   if ((rc = dec_grow(e, Z, (size_t)MP * Lp)) || (rc = dec_grow(e, W1, (size_t)Hr * Lp)) || (rc = dec_grow(e, B1, Hr)) ||
       (rc = dec_grow(e, HID, (size_t)MP * Hp)) || (rc = dec_grow(e, W2, (size_t)Ir * Hp)) || (rc = dec_grow(e, B2, Ir)))
     return rc;
-  auto pad = [&](const float* src, int rows, int cols, float* dst, int rowsP, int colsP) {
-    const int64_t total = (int64_t)rowsP * (colsP / 4);
-    SDRM_LAUNCH(e, k_pad2d, dim3((unsigned)std::min<int64_t>(4096, (total + 255) / 256)), dim3(256), 0, st, src, rows, cols, dst, rowsP, colsP);
-    return hipGetLastError();
-  };
-  HIP_TRY(e, pad(z, n, d->latent, e->dec_buf[Z], MP, Lp));
-  HIP_TRY(e, pad(d->w1, d->hidden, d->latent, e->dec_buf[W1], Hr, Lp));
-  HIP_TRY(e, pad(d->b1, 1, d->hidden, e->dec_buf[B1], 1, Hr));
-  HIP_TRY(e, pad(d->w2, d->n_items, d->hidden, e->dec_buf[W2], Ir, Hp));
-  HIP_TRY(e, pad(d->b2, 1, d->n_items, e->dec_buf[B2], 1, Ir));
+  {
+    PadSegs sg{};
+    int64_t most = 0;
+    int k = 0;
+    auto pad = [&](const float* src, int rows, int cols, float* dst, int rowsP, int colsP) {
+      sg.src[k] = src; sg.dst[k] = dst; sg.rows[k] = rows; sg.cols[k] = cols; sg.rowsP[k] = rowsP; sg.colsP[k] = colsP;
+      most = std::max<int64_t>(most, (int64_t)rowsP * (colsP / 4));
+      ++k;
+    };
+    pad(z, n, d->latent, e->dec_buf[Z], MP, Lp);
+    pad(d->w1, d->hidden, d->latent, e->dec_buf[W1], Hr, Lp);
+    pad(d->b1, 1, d->hidden, e->dec_buf[B1], 1, Hr);
+    pad(d->w2, d->n_items, d->hidden, e->dec_buf[W2], Ir, Hp);
+    pad(d->b2, 1, d->n_items, e->dec_buf[B2], 1, Ir);
+    SDRM_LAUNCH(e, k_pad2d, dim3((unsigned)std::min<int64_t>(2048, (most + 255) / 256), 5), dim3(256), 0, st, sg);
+    HIP_TRY(e, hipGetLastError());
+  }
   const int rows64 = round_up(n, BM);
   const int cfg = choose_cfg(e->tune, rows64, e->tune.nt32_max_rows);
   {
@@ -2171,12 +2185,7 @@ int decode_launches(sdrm_engine* e, const sdrm_vae_decoder* d, const float* z, i
   GemmArgs a{};
   a.C = out; a.ldc = d->n_items; a.bias = e->dec_buf[B2];
   a.rows_valid = n; a.cols_valid = d->n_items;
-  a.hist = &e->sel->hist[0][0][0];
-  const Prof pr{e, PC_FWD_OUT, 2.0 * n * (double)d->n_items * d->hidden};
-  if (with_hist)
-    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_G_HIST>(a, e->dec_buf[HID], Hp, e->dec_buf[W2], Hp, rows64, Ip, Hp, st, pr, cfg)));
-  else
-    HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_G>(a, e->dec_buf[HID], Hp, e->dec_buf[W2], Hp, rows64, Ip, Hp, st, pr, cfg)));
+  HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_G>(a, e->dec_buf[HID], Hp, e->dec_buf[W2], Hp, rows64, Ip, Hp, st, Prof{nullptr, 0, 0.0}, cfg)));
   return SDRM_OK;
 }
 
@@ -2194,30 +2203,7 @@ int sdrm_vae_decode(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z,
   if (int rc = check_decoder(e, dec, z, n, "sdrm_vae_decode")) return rc;
   if (!out) return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode: null output");
   if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
-  return decode_launches(e, dec, z, n, out, false, (hipStream_t)stream);
-}
-
-int sdrm_vae_decode_equal_sparsity(sdrm_engine* e, const sdrm_vae_decoder* dec, const float* z, int n, double q, float* raw_out,
-                                   uint8_t* out, float* threshold, void* stream) {
-  if (int rc = check_decoder(e, dec, z, n, "sdrm_vae_decode_equal_sparsity")) return rc;
-  if (!(q >= 0.0 && q <= 1.0)) return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode_equal_sparsity: q outside [0,1]");
-  if ((raw_out && ((uintptr_t)raw_out & 15u)) || (out && ((uintptr_t)out & 3u)))
-    return fail(e, SDRM_ERR_ARG, "sdrm_vae_decode_equal_sparsity: raw_out must be 16-byte and out 4-byte aligned");
-  hipStream_t st = (hipStream_t)stream;
-  if (int jr = join_chains(e, st)) return jr;
-  const int64_t total = (int64_t)n * dec->n_items;
-  float* raw = raw_out;
-  if (!raw) {   // the caller wants only the 0/1 matrix: the raw scores live in the library's scratch
-    if (int rc = dec_grow(e, 6, (size_t)total)) return rc;
-    raw = e->dec_buf[6];
-  }
-  int64_t r0, r1;
-  float gamma;
-  quantile_ranks(total, q, r0, r1, gamma);
-  SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
-  HIP_TRY(e, hipGetLastError());
-  if (int rc = decode_launches(e, dec, z, n, raw, true, st)) return rc;
-  return select_and_binarize(e, raw, total, gamma, 1, out, threshold, st);
+  return decode_launches(e, dec, z, n, out, (hipStream_t)stream);
 }
 
 int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uint8_t* out, float* threshold, void* stream) {
@@ -2232,7 +2218,7 @@ int sdrm_equal_sparsity(sdrm_engine* e, const float* x, int64_t n, double q, uin
   quantile_ranks(n, q, r0, r1, gamma);
   SDRM_LAUNCH(e, k_select_init, dim3(8), dim3(256), 0, st, e->sel, r0, r1);
   HIP_TRY(e, hipGetLastError());
-  return select_and_binarize(e, x, n, gamma, 0, out, threshold, st);
+  return select_and_binarize(e, x, n, gamma, out, threshold, st);
 }
 
 // ---------------------------------------------------------------------------------------------

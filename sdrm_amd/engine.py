@@ -124,6 +124,26 @@ class Engine:
     def get_params(self):
         return self._flat_out(self.lib.sdrm_get_params, "sdrm_get_params")
 
+    def params_view(self):
+        """The live parameters in place (sdrm_params_ptr): a [P] float32 tensor that ALIASES the engine's master vector - it follows
+        every train step without a copy.  Read it; do not write through it (the kernels read compute copies of it)."""
+        class _Span:   # what torch.as_tensor needs to wrap foreign device memory
+            pass
+        span = _Span()
+        span.__cuda_array_interface__ = {"shape": (self.P,), "typestr": "<f4", "data": (int(self.lib.sdrm_params_ptr(self._h)), False), "version": 2}
+        t = torch.as_tensor(span, device=self.device)
+        t._sdrm_owner = self   # the memory lives as long as the engine
+        return t
+
+    def philox_draws(self, seed, purpose, step, rows, quads, row0=0, with_bits=True):
+        """Test hook (sdrm_debug_philox_draws): the device generator's normals [rows, 4 * quads] and the low three bits of its
+        words [rows, 4 * quads] uint8 for (seed, purpose, step)."""
+        normals = torch.empty(rows, 4 * quads, dtype=torch.float32, device=self.device)
+        bits = torch.empty(rows, 4 * quads, dtype=torch.uint8, device=self.device) if with_bits else None
+        self._check(self.lib.sdrm_debug_philox_draws(self._h, int(seed), int(purpose), int(step), int(row0), int(rows), int(quads),
+                                                     _ptr(normals), _ptr(bits), _stream()), "sdrm_debug_philox_draws")
+        return normals, bits
+
     def get_grads(self):
         return self._flat_out(self.lib.sdrm_get_grads, "sdrm_get_grads")
 
@@ -398,20 +418,6 @@ class Engine:
         out = torch.empty(z.shape[0], n_items, dtype=torch.float32, device=self.device)
         self._check(self.lib.sdrm_vae_decode(self._h, C.byref(dec), _ptr(z), z.shape[0], _ptr(out), _stream()), "sdrm_vae_decode")
         return out
-
-    def vae_decode_equal_sparsity(self, z, w1, b1, w2, b2, sparsity, keep_raw=True):
-        """Decode + main.py:177-180 in one call: (binary uint8 [n, items], threshold 0-d tensor, raw scores or None)."""
-        dec, latent, n_items = self._decoder(w1, b1, w2, b2)
-        z = self._dev(z, torch.float32)
-        if z.dim() != 2 or z.shape[1] != latent:
-            raise SdrmError(f"vae_decode_equal_sparsity: z must be [n,{latent}]")
-        n = z.shape[0]
-        raw = torch.empty(n, n_items, dtype=torch.float32, device=self.device) if keep_raw else None
-        out = torch.empty(n, n_items, dtype=torch.uint8, device=self.device)
-        thr = torch.empty((), dtype=torch.float32, device=self.device)
-        self._check(self.lib.sdrm_vae_decode_equal_sparsity(self._h, C.byref(dec), _ptr(z), n, float(sparsity), _ptr(raw), _ptr(out),
-                                                            _ptr(thr), _stream()), "sdrm_vae_decode_equal_sparsity")
-        return out, thr, raw
 
     def csr_to_device(self, m):
         """(indptr i64, indices i32, data f32 | None for an all-ones matrix, shape) of a scipy sparse matrix, on the device."""

@@ -17,12 +17,11 @@ by `torch.initial_seed()`-derived seeds; explicit randoms can be injected for pa
 
 Differences a caller can observe (all documented in DESIGN.md): the latents of the frozen eval-mode VAE
 are identical to the reference's (z = mu(x)); `loss.item()` is not called per step (Q14), the per-step
-loss stays on the device in `DIFF.last_loss`; `SDRM.parameters()` returns snapshots (the live
-parameters sit in the engine, `state_dict()/load_state_dict()` move them in and out)."""
+loss stays on the device in `DIFF.last_loss`; `SDRM.parameters()` returns read-only views of the engine's live
+parameters (`EngineParameter`: in-place writes raise; `state_dict()/load_state_dict()` move them in and out)."""
 from __future__ import annotations
 
 import math
-import os
 import time
 import warnings
 from collections import OrderedDict
@@ -32,9 +31,9 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import metrics as utilities
 from . import synth
-from .engine import Engine, SdrmError, utility_engine
+from .engine import Engine, SdrmError
+from .vae_hooks import VAE, checkpoint, resume, train_variational_autoencoder  # noqa: F401  (part of the reference's module surface)
 
 warnings.filterwarnings("ignore")
 
@@ -45,30 +44,22 @@ DEVICE = "cuda" if torch.cuda.is_available() else "cpu"
 b_t = a_t = ab_t = None
 
 
-def _pruned(msg):
-    try:  # the reference signals VAE checkpoint IO failures to Optuna (:72,:83)
-        import optuna  # type: ignore
-        return optuna.TrialPruned(msg)
-    except Exception:
-        return RuntimeError(msg)
+# --------------------------------------------------------------------------------------------------
+class EngineParameter(torch.Tensor):
+    """A view of the engine's live parameter vector.  Reads behave like any tensor; in-place writes raise: the engine's kernels
+    read padded / transposed / fragment-packed copies that only `load_state_dict` and the train step refresh, so an optimiser
+    stepping these tensors would change nothing the net computes with (the reference's callers never do: they only call
+    `train_SDRM`, `diff_net.eval()` and `diff_net.forward`, hyperparameter_search.py:53,67,78)."""
 
-
-def checkpoint(model, filename, VAE_DIR_PATH):
-    """Save model parameters to file (:75-83)."""
-    try:
-        torch.save(model.state_dict(), os.path.normpath(os.path.join(VAE_DIR_PATH, filename)))
-    except Exception:
-        print("Failed to save model parameters to %s" % filename)
-        raise _pruned("checkpoint failed")
-
-
-def resume(model, filename, VAE_DIR_PATH):
-    """Load model parameters from file (:66-72)."""
-    try:
-        model.load_state_dict(torch.load(os.path.normpath(os.path.join(VAE_DIR_PATH, filename))))
-    except Exception:
-        print("Failed to load model parameters from %s" % filename)
-        raise _pruned("resume failed")
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        name = getattr(func, "__name__", "")
+        if (name.endswith("_") and not name.endswith("__")) or name in ("__setitem__", "__iadd__", "__isub__", "__imul__", "__itruediv__"):
+            raise SdrmError(f"in-place {name} on a parameter of an engine-backed SDRM: its parameters are updated by the engine's train "
+                            "step (train_SDRM / Engine.train_step) or replaced with load_state_dict()")
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **(kwargs or {}))
+        return out
 
 
 # --------------------------------------------------------------------------------------------------
@@ -132,14 +123,33 @@ class SDRM:
     def eval(self):
         return self.train(False)  # dropout stays on regardless (F.dropout default, Q2)
 
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    def cpu(self):
+        raise SdrmError("this SDRM lives in the HIP engine on a ROCm device (no CPU path); use state_dict() to take its parameters to the host")
+
+    def zero_grad(self, set_to_none=True):
+        return None   # gradients live in the engine and are overwritten by every backward
+
+    def modules(self):
+        return iter([self])
+
     def _flat(self):
-        return self._engine.get_params() if self._engine is not None else self._pending
+        return self._engine.params_view() if self._engine is not None else self._pending
 
     def named_parameters(self):
+        """The reference's `named_parameters()` order (a13).  With a live engine the tensors ALIAS the engine's parameter vector (they
+        follow every train step, like an nn.Module's parameters); they are `EngineParameter`s: reading is free, an in-place write raises,
+        and torch.optim refuses them when it is built (they are views, not leaves) instead of silently training a copy."""
         flat, off = self._flat(), 0
+        live = self._engine is not None
+        if live:   # views of a leaf that requires grad: torch.optim refuses them at construction ("can't optimize a non-leaf Tensor")
+            flat = flat.requires_grad_(True)
         for name, shp in ((n, synth.param_shapes(self.L, self.W, self.T, self.H)[n]) for n in synth.param_names(self.H)):
             k = int(np.prod(shp))
-            yield name, flat[off:off + k].reshape(shp)
+            v = flat[off:off + k].reshape(shp)
+            yield name, (v.as_subclass(EngineParameter) if live else v)
             off += k
 
     def parameters(self):
@@ -147,7 +157,7 @@ class SDRM:
 
     def state_dict(self):
         """Reference key layout, including the aliased keys of the shared hidden layer (dnn.4.* ...)."""
-        sd = OrderedDict((n, p.detach().clone()) for n, p in self.named_parameters())
+        sd = OrderedDict((n, p.as_subclass(torch.Tensor).detach().clone()) for n, p in self.named_parameters())
         out = OrderedDict()
         last = 2 + 2 * self.H
         aliases = synth.alias_keys(self.H)
@@ -188,111 +198,6 @@ class SDRM:
         if dim % 2:
             emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
         return emb
-
-
-# --------------------------------------------------------------------------------------------------
-class VAE(nn.Module):
-    """MultiVAE++ (:206-268), PyTorch: the encode/decode hooks the denoising engine sits between."""
-
-    def __init__(self, input_dim, hidden_dim, latent_dim, p_drop=0.5):
-        super().__init__()
-        self.latent_dim = latent_dim
-        self.encoder = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.Tanh(), nn.Linear(hidden_dim, 2 * latent_dim))
-        self.decoder = nn.Sequential(nn.Linear(latent_dim, hidden_dim), nn.Tanh(), nn.Linear(hidden_dim, input_dim))
-        self.dropout = nn.Dropout(p=p_drop)
-        self.model_is_trained = False
-        self.is_training = 0
-        self.weight_decay = 0
-        for m in self.modules():
-            if isinstance(m, nn.Linear):
-                nn.init.xavier_uniform_(m.weight.data)
-                m.bias.data.normal_(0.0, 0.001)
-
-    def encode(self, x):
-        h = self.encoder(self.dropout(F.normalize(x, p=2, dim=1)))
-        mu, logvar = torch.chunk(h, chunks=2, dim=1)
-        kl = -0.5 * torch.mean(torch.sum(1 + logvar - mu.pow(2) - logvar.exp(), dim=1))
-        eps = torch.randn_like(mu)  # consumed even in eval, like the reference (Q12)
-        return mu + self.is_training * eps * torch.exp(0.5 * logvar), kl
-
-    def decode(self, z):
-        return self.decoder(z)
-
-    def forward(self, x):
-        z, kl = self.encode(x)
-        return self.decode(z), kl
-
-    def get_l2_reg(self):
-        if self.weight_decay <= 0:
-            return torch.zeros((), device=next(self.parameters()).device)
-        return self.weight_decay * sum(torch.norm(p, p=2) ** 2 for n, p in self.named_parameters() if n.endswith(".weight"))
-
-    def sample(self, n_samples):
-        z = torch.randn(n_samples, self.latent_dim, device=next(self.parameters()).device)
-        return self.decode(z).cpu().detach().numpy()
-
-
-def train_variational_autoencoder(model, train_data, test_data, epochs, batch_size, lr, early_stop_metric="NDCG@50",
-                                  VAE_DIR_PATH="./", verbose=False):
-    """VAE pre-stage (:115-188): multinomial NLL + annealed KL, early stopping on Recall/NDCG@k of a
-    per-user hold-out of `test_data`, best epoch restored.  Plain PyTorch (not part of the hot path)."""
-    os.makedirs(os.path.normpath(VAE_DIR_PATH), exist_ok=True)
-    dev = next(model.parameters()).device
-    anneal_cap, anneal_count = 0.2, 0.0
-    best_metric, best_epoch, stale = -np.inf, 0, 0
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
-    k = int(early_stop_metric.split("@")[1])
-    start = time.time()
-    for epoch in range(epochs):
-        losses = []
-        model.train()
-        model.is_training = 1
-        train_data = train_data[np.random.permutation(train_data.shape[0])]
-        for lo in range(0, train_data.shape[0], batch_size):
-            hi = min(lo + batch_size, train_data.shape[0])
-            anneal = min(anneal_cap, 1.0 * anneal_count / 20_000)
-            X = torch.tensor(train_data[lo:hi].toarray(), dtype=torch.float32, device=dev)
-            optimizer.zero_grad()
-            out, kl = model(X)
-            neg_ll = -torch.mean(torch.sum(F.log_softmax(out, dim=1) * X, dim=1))
-            loss = neg_ll + anneal * kl + model.get_l2_reg()
-            losses.append(loss.item())
-            loss.backward()
-            optimizer.step()
-            anneal_count += 1
-        model.eval()
-        model.is_training = 0
-        scores = []
-        valid_train, valid_test = utilities.split_train_test_proportion_from_csr_matrix(test_data, batch_size=1000)
-        with torch.no_grad():
-            for lo in range(0, valid_train.shape[0], 500):
-                hi = min(lo + 500, valid_train.shape[0])
-                X = valid_train[lo:hi]
-                pred, _ = model(torch.tensor(X.toarray(), dtype=torch.float32, device=dev))
-                if dev.type == "cuda":
-                    # utilities.py:116-171 on the device (sdrm_rank_metrics): the [500, N_ITEMS] scores stay in HBM
-                    rec, ndcg = utility_engine(dev).rank_metrics(pred, valid_test[lo:hi], train=X, ks=(k,))
-                    scores.append((rec if "Recall" in early_stop_metric else ndcg)[0].cpu().numpy())
-                else:
-                    pred = utilities.mask_training_examples(X, pred.cpu().numpy())
-                    fn = utilities.recall_at_k_batch if "Recall" in early_stop_metric else utilities.NDCG_binary_at_k_batch
-                    scores.append(fn(pred, valid_test[lo:hi], k=k))
-        avg = np.nanmean(np.concatenate(scores))
-        if verbose:
-            print(f"Epoch: {epoch}, Loss: {np.round(np.mean(losses), 4)}, {early_stop_metric}: {np.round(avg, 4)}", end="\r")
-        if avg > best_metric:
-            best_metric, best_epoch, stale = avg, epoch, 0
-            checkpoint(model, f"epoch-{epoch}.pth", VAE_DIR_PATH)
-        else:
-            stale += 1
-            if stale > 20:
-                if verbose:
-                    print(f"MultiVAE++ training complete. Early stopping at epoch {epoch}, "
-                          f"Training took {np.round((time.time() - start) / 60, 2)} minutes")
-                break
-    resume(model, f"epoch-{best_epoch}.pth", VAE_DIR_PATH)
-    model.model_is_trained = True
-    model.is_training = 0
 
 
 # --------------------------------------------------------------------------------------------------
@@ -398,12 +303,11 @@ def _decode(eng, vae_net, latents):
 
 
 def engine_decode_pays(n_users: int, hidden: int, n_items: int) -> bool:
-    """Where the engine's decode beats the PyTorch module it replaces (measured, profiles/r02_next_rows_bench.txt and
-    r03_next_rows_bench.txt): ML-1M (5429 x 3125, hidden 600) 246 us against 301; ML-100k (843 x 1008) 60 against 53 - five
-    staging launches on a 0.8 GFLOP problem - and ADM (9558 x 8582, hidden 200: a 200-deep contraction) 414 against 403 lose.
-    So: a hidden width that fills the K loop, and enough work to amortise the staging.  `sdrm_vae_decode` itself is correct at
-    every shape (tests/test_vae_decode.py); this only routes the hook."""
-    return hidden >= 256 and float(n_users) * float(n_items) * float(hidden) >= 4e9
+    """Where the engine's decode beats the PyTorch module it replaces: since round 4 (the five staging launches became one) at
+    every BASELINE shape - ML-100k (843 x 1008) 50 us against 62, ML-1M (5429 x 3125) 224 against 294, ADM (9558 x 8582) 361
+    against 381 (profiles/r04_next_rows_bench.txt) - so the hook is always routed to the engine; kept as the one place to change
+    that."""
+    return True
 
 
 @torch.no_grad()

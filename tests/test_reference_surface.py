@@ -76,6 +76,31 @@ def test_state_dict_through_engine():
     assert torch.equal(before, a.engine().get_params()) and a.engine().get_adam_state()[2] == 1
 
 
+def test_parameters_are_live_views_and_refuse_writes():
+    """`SDRM.parameters()` (hyperparameter_search.py:53 passes nets around like any nn.Module): with a live engine the tensors alias
+    the engine's parameter vector - they follow a train step without being fetched again - and an in-place write (what an external
+    torch.optim would do) raises instead of silently training a copy; `.cuda()`, `.zero_grad()`, `.modules()` exist."""
+    import sdrm_amd.train_SDRM as ts
+    from sdrm_amd.engine import SdrmError
+    net = ts.SDRM(16, 6, 24, 2).cuda()
+    eng = net.engine(8)
+    params = dict(net.named_parameters())
+    before = {n: p.as_subclass(torch.Tensor).clone() for n, p in params.items()}
+    assert float((params["dnn.0.weight"] * 2).sum()) == float(before["dnn.0.weight"].sum() * 2)      # reads are ordinary tensor ops
+    eng.train_step(torch.randn(8, 16, device="cuda"), 1e-2, seed=1, step=0)
+    torch.cuda.synchronize()
+    assert all(not torch.equal(p.as_subclass(torch.Tensor), before[n]) for n, p in params.items())    # the same objects see the update
+    assert torch.equal(torch.cat([p.as_subclass(torch.Tensor).reshape(-1) for p in net.parameters()]), eng.get_params())
+    with pytest.raises((SdrmError, RuntimeError)):
+        params["dnn.0.bias"].add_(1.0)
+    with pytest.raises(ValueError, match="non-leaf"):       # an external optimiser cannot be built over them
+        torch.optim.SGD(net.parameters(), lr=0.1)
+    net.zero_grad()
+    assert list(net.modules()) == [net]
+    with pytest.raises(SdrmError):
+        net.cpu()
+
+
 def test_cache_latents_matches_per_batch_encoding(tmp_path):
     """encoding the feed once gives the same trained eps-net as encoding per batch."""
     import sdrm_amd.train_SDRM as ts

@@ -61,7 +61,7 @@ for name, (latent, hidden, items, users, q) in {"ML-100k": (830, 930, 1008, 843,
         us_torch = timed(lambda: vae.decode(z))
         us_torch_chain = timed(lambda: e.equal_sparsity(vae.decode(z), q))
     us_dec = timed(lambda: e.vae_decode(z, *tensors))
-    us_chain = timed(lambda: e.vae_decode_equal_sparsity(z, *tensors, q, keep_raw=False))
+    us_chain = timed(lambda: e.equal_sparsity(e.vae_decode(z, *tensors), q))
     flops = 2.0 * users * (latent * hidden + hidden * items)
     res["decode_" + name] = {"users": users, "items": items, "latent": latent, "hidden": hidden,
                              "engine_decode_us": round(us_dec, 1), "engine_decode_TF": round(flops / us_dec / 1e6, 1),
