@@ -497,6 +497,8 @@ struct Job {
   int flat_ld;
   int ncols;          // columns [0,ncols) of each row have a compute copy (dnn.0.weight: L of L+T)
   float* dst; int dst_ld;                                          // compute copy (may be null)
+  float* dst2; int dst2_ld;                                        // a second padded copy, of columns [ncols, cols) (the embedding columns of
+                                                                   // dnn.0.weight for the narrow nets' forward; may be null)
   float* dstT; int dstT_ld;                                        // transposed compute copy [col][row] (may be null)
   float* dstF; float* dstFT; int fnct;                             // fragment-packed copies of the matrix / of its transpose for the
                                                                    // row-owned kernels (rowchain.h; may be null), fnct column tiles
@@ -599,6 +601,7 @@ __global__ __launch_bounds__(256) void k_adam(const JobTable tab, const AdamArgs
     const int r = (int)(i / jb.cols), c = (int)(i - (int64_t)r * jb.cols);
     const float w = adam_element(a, jb.flat_off + (int64_t)r * jb.flat_ld + c);
     if (jb.dst != nullptr && c < jb.ncols) jb.dst[(size_t)r * jb.dst_ld + c] = w;
+    if (jb.dst2 != nullptr && c >= jb.ncols) jb.dst2[(size_t)r * jb.dst2_ld + c - jb.ncols] = w;
     if (jb.dstF != nullptr && c < jb.ncols) jb.dstF[wfrag_index(r, c, jb.fnct, jb.fklast)] = w;
   }
 }

@@ -97,6 +97,8 @@ struct sdrm_engine {
   float *alpha_part = nullptr;
   int alpha_part_stride = 0;
   double *loss_part = nullptr, *sums = nullptr;
+  float *WeP = nullptr, *W0eP = nullptr;    // narrow nets with T <= 128: padded copies of emb_layer.weight [TPe][TPe] and of W0e [WP][TPe]
+  int TPe = 0;                              // (TPe = T rounded up to 16): the forward makes its own rows of the time-embedding table
   float *Mred = nullptr, *snap = nullptr;   // the tail's hand-over to its second launch (csrc/tail.h): M [W][TP]; We | be | W0e before the update
   int *tdev = nullptr;
   int64_t *Tj_dev = nullptr;
@@ -439,14 +441,16 @@ void build_jobs(sdrm_engine* e, JobTable& tab) {
   auto add = [&](int64_t off, int rows, int cols, int flat_ld, int ncols, float* dst, int dst_ld, float* dstT = nullptr, int dstT_ld = 0) -> Job& {
     Job& j = tab.j[n++];
     j.flat_off = off; j.rows = rows; j.cols = cols; j.flat_ld = flat_ld; j.ncols = ncols;
-    j.dst = dst; j.dst_ld = dst_ld; j.dstT = dstT; j.dstT_ld = dstT_ld;
+    j.dst = dst; j.dst_ld = dst_ld; j.dstT = dstT; j.dstT_ld = dstT_ld; j.dst2 = nullptr; j.dst2_ld = 0;
     j.dstF = nullptr; j.dstFT = nullptr; j.fnct = e->WP / 16; j.fklast = -1; j.fklastT = -1;
     return j;
   };
-  add(e->off_we, 1, T * T + T, T * T + T, 0, nullptr, 0);   // emb_layer.weight + emb_layer.bias (no compute copy)
+  add(e->off_we, T, T, T, e->WeP ? T : 0, e->WeP, e->TPe);   // emb_layer.weight (a padded copy for the narrow nets' forward only)
+  add(e->off_be, 1, T, T, 0, nullptr, 0);                    // emb_layer.bias
   {
     Job& j = add(e->off_w0, W, L + T, L + T, L, e->W0c, e->K0);
     j.dstF = e->W0f; j.fklast = rc_light_klast(L, e->LP);
+    j.dst2 = e->W0eP; j.dst2_ld = e->TPe;
   }
   add(e->off_b0, 1, W, W, W, e->b0c, 0);
   add(e->off_a0, 1, 1, 1, 1, nullptr, 0);
@@ -720,6 +724,7 @@ SkStepArgs sk_step_args(sdrm_engine* e, int B) {
   const int n = e->T + 1;
   a.W0c = e->W0c; a.K0 = e->K0; a.Whc = e->Whc; a.Woc = e->Woc; a.bh = e->bhc; a.bo = e->boc;
   a.WhcT = e->WhcT; a.WocT = e->WocT; a.B0tab = e->B0tab;
+  a.WeP = e->WeP; a.W0eP = e->W0eP; a.be = e->p + e->off_be; a.b0 = e->b0c; a.TPe = e->TPe; a.intab = e->WeP ? 1 : 0;
   a.slope0 = slope_ptr(e, 0); a.slopeh = e->H > 0 ? slope_ptr(e, 1) : slope_ptr(e, 0);
   a.sqrt_ab = e->sched + 3 * n; a.one_minus_ab = e->sched + 4 * n; a.tembP = e->tembP;
   a.B = B; a.L = e->L; a.W = e->W; a.T = e->T; a.H = e->H; a.G = (B + SK_USERS - 1) / SK_USERS;
@@ -734,7 +739,7 @@ SkStepArgs sk_step_args(sdrm_engine* e, int B) {
 template <int NL, int NW>
 int launch_sk_step_nlnw(sdrm_engine* e, const SkStepArgs& ka, int which, int grid, hipStream_t st) {
   typedef SkCfg<NL, NW> C;
-  const size_t lds = (which == 0 ? sk_fwd_lds_floats<NL, NW>() : sk_bwd_lds_floats<NL, NW>(ka.TPs)) * sizeof(float);
+  const size_t lds = (which == 0 ? sk_fwd_lds_floats<NL, NW>(ka.intab ? ka.TPe : 0) : sk_bwd_lds_floats<NL, NW>(ka.TPs)) * sizeof(float);
   if (lds > 48 * 1024) {
     if (which == 0) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_bwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1079,6 +1084,10 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   e->alpha_part_stride = std::max(max_gemm_blocks((int)MP, e->WP), (int)MP / 16);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
   HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, MP / SK_ROWS + 1))); HIP_TRY(e, dalloc(&e->sums, 8));
+  if (e->LP <= 64 && e->WP <= 64 && T <= 128) {
+    e->TPe = round_up(T, 16);
+    HIP_TRY(e, dalloc(&e->WeP, (size_t)e->TPe * e->TPe)); HIP_TRY(e, dalloc(&e->W0eP, (size_t)e->WP * e->TPe));
+  }
   HIP_TRY(e, dalloc(&e->Mred, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->snap, (size_t)T * T + T + (size_t)W * T));
   if (tail_emb_lds_floats(T, e->TP) * sizeof(float) > 48 * 1024)
     HIP_TRY(e, hipFuncSetAttribute((const void*)k_tail_emb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tail_emb_lds_floats(T, e->TP) * sizeof(float))));
@@ -1101,7 +1110,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->tembP, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1201,7 +1210,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   if (skinny_net(e)) {
     // narrow net (csrc/skinny_step.h): staging, all layers and the loss partial sums of 16 users' P, S, Q rows per work-group in
     // ONE launch; the tables B0tab = b0 + C0[t] come from the last step's tail (or are made now, after a parameter upload)
-    int rc = ensure_tables(e, st);
+    int rc = e->WeP ? SDRM_OK : ensure_tables(e, st);   // (T <= 128: the forward makes its users' rows of the table itself)
     if (rc) return rc;
     SkStepArgs ka = sk_step_args(e, B);
     ka.x0 = x0;
@@ -1512,7 +1521,7 @@ int backward_tail(sdrm_engine* e, float* gout, int which, bool update, float lr,
   a.p = e->p; a.m = e->m; a.v = e->v; a.g = gout;
   a.L = L; a.W = W; a.T = T; a.LP = e->LP; a.TP = e->TP;
   a.off_we = e->off_we; a.off_be = e->off_be; a.off_w0 = e->off_w0; a.off_b0 = e->off_b0;
-  a.Mred = e->Mred; a.snap = e->snap;
+  a.Mred = e->Mred; a.snap = e->snap; a.WeP = e->WeP; a.W0eP = e->W0eP; a.TPe = e->TPe;
   a.b1 = 0.9f; a.b2 = 0.999f; a.eps = 1e-8f; a.wd = 1e-4f; a.update = update ? 1 : 0;
   if (update) adam_scalars(e, lr, a.step_size, a.bc2_sqrt);
   static unsigned long long* g_tstamps = nullptr; static int g_tcount = 0;   // TEMP diagnostic

@@ -34,7 +34,10 @@ struct SkStepArgs {
   // net: padded compute copies, the per-timestep layer-0 bias table, slopes
   const float* W0c; int K0; const float* Whc; const float* Woc; const float* bh; const float* bo;
   const float* WhcT; const float* WocT;   // [in][out] copies (backward)
-  const float* B0tab;                     // [T+1][WPs] = b0 + C0[t]
+  const float* B0tab;                     // [T+1][WPs] = b0 + C0[t] (used when intab == 0)
+  // intab: the forward makes its 16 users' rows of that table itself (no tables launch in front of the step): E = temb[t] * We^T
+  // + be, then b0 + E * W0e^T, from the padded copies WeP [TPe][TPe], W0eP [WPs][TPe] (TPe = T rounded up to 16, at most 128)
+  const float* WeP; const float* W0eP; const float* be; const float* b0; int TPe, intab;
   const float* slope0; const float* slopeh;
   const float* sqrt_ab; const float* one_minus_ab;
   const float* tembP;                     // [T+1][TPs] time-embedding table, rows padded with zeros
@@ -67,7 +70,11 @@ struct SkCfg {
 // dynamic LDS (floats): forward: two tiles; backward: two gradient tiles, two input tiles, the pass-summed dpre0 tile [16][SCR],
 // the users' time-embedding rows [16][TPs + 4], bias column sums [3 kinds][3 passes][64], slope partials [32 applications][12 waves]
 template <int NL, int NW>
-__host__ __device__ constexpr size_t sk_fwd_lds_floats() { return 2 * (size_t)SkCfg<NL, NW>::TILE + 16 + 2 * 4 * 12 + 16 * (size_t)SkCfg<NL, NW>::SCR; }   // + trow [16], loss sums [12 waves][4] doubles, x0 [16][SCR]
+__host__ __device__ inline size_t sk_fwd_lds_floats(int TPe) {   // + trow [16], loss sums [12 waves][4] doubles, x0 [16][SCR], B0 rows [16][SCR];
+  // intab (TPe > 0): E rows and temb rows [16][TPe + 4] each, emb_layer.weight [TPe][TPe + 4], W0e [16 NW][TPe + 4]
+  return 2 * (size_t)SkCfg<NL, NW>::TILE + 16 + 2 * 4 * 12 + 2 * 16 * (size_t)SkCfg<NL, NW>::SCR +
+         (TPe > 0 ? (size_t)(32 + TPe + SkCfg<NL, NW>::WPk) * (TPe + 4) : 0);
+}
 template <int NL, int NW>
 __host__ __device__ inline size_t sk_bwd_lds_floats(int TPs) {
   return 4 * (size_t)SkCfg<NL, NW>::TILE + SK_USERS * (size_t)SkCfg<NL, NW>::SCR + SK_USERS * (size_t)(TPs + 4) + 3 * 3 * 64 + 32 * 12 + 64;
@@ -84,6 +91,11 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
   int* trow = reinterpret_cast<int*>(sksh + 2 * C::TILE);          // [16]
   double* red = reinterpret_cast<double*>(sksh + 2 * C::TILE + 16);   // [12 waves][4] (8-byte aligned: TILE is a multiple of 4 floats)
   float* x0s = sksh + 2 * C::TILE + 16 + 2 * 4 * 12;                   // [16][SCR]: the group's x0 rows (loss sums)
+  float* B0s = x0s + 16 * SCR;                                         // [16][SCR]: b0 + C0[t_user] (intab)
+  float* Es = B0s + 16 * SCR;                                          // [16][TPe + 4]: E[t_user] (intab)
+  float* Ts = Es + 16 * (a.TPe + 4);                                   // [16][TPe + 4]: temb[t_user] (intab)
+  float* WeS = Ts + 16 * (a.TPe + 4);                                  // [TPe][TPe + 4]: emb_layer.weight (intab; loaded once per work-group)
+  float* W0eS = WeS + a.TPe * (a.TPe + 4);                             // [16 NW][TPe + 4]: W0e (intab)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pass = wave / NV, ct = wave - pass * NV;
@@ -103,6 +115,19 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
     bov = a.bo[col];
   }
   const float slope0 = *a.slope0, slopeh = a.H > 0 ? *a.slopeh : 0.f;
+  // intab: emb_layer.weight and W0e into LDS, once per work-group (B operands of the two embedding products: out of registers
+  // they pushed the kernel past its 168-register budget, 240 bytes of scratch per lane and 10 us)
+  const int nke = a.TPe >> 4, lde = a.TPe + 4;
+  float b0c_ = 0.f;
+  if (a.intab) {
+    const int qpr = a.TPe >> 2;
+    for (int f = tid; f < (a.TPe + C::WPk) * qpr; f += NTHR) {
+      const int r = f / qpr, q = f - r * qpr;
+      const float* src = r < a.TPe ? a.WeP + (size_t)r * a.TPe + 4 * q : a.W0eP + (size_t)(r - a.TPe) * a.TPe + 4 * q;
+      *reinterpret_cast<f32x4*>(WeS + r * lde + 4 * q) = *reinterpret_cast<const f32x4*>(src);   // (W0eS follows WeS with the same row stride)
+    }
+    if (pass == 0 && ct < NW) b0c_ = a.b0[col];
+  }
 
   SK_STAMP(0);
   for (int g = blockIdx.x; g < a.G; g += gridDim.x) {
@@ -143,11 +168,21 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
     }
     lds_barrier();
     SK_STAMP(1);
-    // layer 0's time-embedding term + bias: the table row of each accumulator row's timestep - in flight under the staging
+    // layer 0's time-embedding term + bias: the table row of each accumulator row's timestep - in flight under the staging.
+    // intab: the operands of E = temb[t_user] * We^T instead (wave w < TPe / 16 makes column tile w of it): the users' temb rows
+    // as A fragments, the wave's rows of We as B fragments, all requested now
     float b0v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ct < NW) {
+    f32x4 tq = {0.f, 0.f, 0.f, 0.f};   // intab: this thread's 16 bytes of the users' temb rows (requested now, to LDS behind the staging)
+    float bev = 0.f;
+    if (!a.intab) {
+      if (ct < NW) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) b0v[r] = a.B0tab[(size_t)max(trow[4 * lq + r], 0) * a.WPs + col];
+        for (int r = 0; r < 4; ++r) b0v[r] = a.B0tab[(size_t)max(trow[4 * lq + r], 0) * a.WPs + col];
+      }
+    } else {
+      const int qpr = a.TPe >> 2;   // at most 32 quads per row: 16 rows are at most 512 threads' worth (NTHR >= 192: a loop)
+      if (tid < 16 * qpr && trow[tid / qpr] >= 0) tq = *reinterpret_cast<const f32x4*>(a.tembP + (size_t)trow[tid / qpr] * a.TPs + 4 * (tid % qpr));
+      if (wave < nke) bev = wave * 16 + li < a.T ? a.be[wave * 16 + li] : 0.f;
     }
     // ---- staging: the three pass waves of a column tile draw the same Philox words (the noise is shared by the passes, the keep
     // bits are bits 0..2 of the same words)
@@ -177,8 +212,51 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
       *reinterpret_cast<f32x4*>(a.U + (grow0 + 16 * pass + ur) * a.K0 + c0) = uv;
       if (pass == 1) *reinterpret_cast<f32x4*>(&x0s[ur * SCR + c0]) = f32x4{xs[0], xs[1], xs[2], xs[3]};   // x0 for the loss sums
     }
+    if (a.intab) {
+      // the users' temb rows -> LDS; E rows of the 16 users (wave w: column tile w); b0 + E * W0e^T (pass-0 waves: column tile ct)
+      const int qpr = a.TPe >> 2;
+      if (tid < 16 * qpr) *reinterpret_cast<f32x4*>(Ts + (tid / qpr) * lde + 4 * (tid % qpr)) = tq;
+      for (int f = tid + NTHR; f < 16 * qpr; f += NTHR) {   // (work-groups of fewer than 16 * qpr threads)
+        const int r = f / qpr, q = f - r * qpr;
+        *reinterpret_cast<f32x4*>(Ts + r * lde + 4 * q) =
+            trow[r] >= 0 ? *reinterpret_cast<const f32x4*>(a.tembP + (size_t)trow[r] * a.TPs + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      lds_barrier();   // (also: the staging's tile is complete)
+      for (int tl = wave; tl < nke; tl += C::NWAVES) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int u = 0; u < nke; ++u) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(Ts + li * lde + 16 * u + 4 * lq);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(WeS + (tl * 16 + li) * lde + 16 * u + 4 * lq);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
+        }
+        const float bej = tl == wave ? bev : (tl * 16 + li < a.T ? a.be[tl * 16 + li] : 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Es[(4 * lq + r) * lde + tl * 16 + li] = tl * 16 + li < a.T ? acc0[r] + acc1[r] + bej : 0.f;
+      }
+      lds_barrier();
+      if (pass == 0 && ct < NW) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (int u = 0; u < nke; ++u) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(Es + li * lde + 16 * u + 4 * lq);
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(W0eS + (ct * 16 + li) * lde + 16 * u + 4 * lq);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B0s[(4 * lq + r) * SCR + col] = acc0[r] + acc1[r] + b0c_;
+      }
+    }
     lds_barrier();
     SK_STAMP(2);
+    if (a.intab && ct < NW) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b0v[r] = B0s[(4 * lq + r) * SCR + col];
+    }
 
     // ---- layer 0: latent part by MFMA, time-embedding part + bias from the table
     if (ct < NW) {

@@ -62,6 +62,9 @@ struct TailArgs {
   int64_t off_we, off_be, off_w0, off_b0;
   // the second launch's inputs, made by the first: M [W][TP] and the pre-update snapshot We [T][T] | be [T] | W0e [W][T]
   float* Mred; float* snap;
+  // narrow nets: padded copies of emb_layer.weight [TPe][TPe] and of W0e [WP][TPe] (TPe = T rounded up to 16) that the forward
+  // multiplies the users' time-embedding rows with (skinny_step.h); null otherwise
+  float* WeP; float* W0eP; int TPe;
   float step_size, bc2_sqrt, b1, b2, eps, wd;
   int update;
   unsigned long long* stamps;   // diagnostic runs only (SDRM_TAIL_STAMPS): 8 slots per work-group of k_tail
@@ -352,7 +355,10 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
     int i = 0;
     for (; i + 1 < T; i += 2) { s0 = fmaf(mr[i], wr[i], s0); s1 = fmaf(mr[i + 1], wr[i + 1], s1); }
     if (i < T) s0 = fmaf(mr[i], wr[i], s0);
-    if (own) tail_apply_pre(a, fi, (s0 + s1) + db0S[r] * beS[jj], ow, om, ov);
+    if (own) {
+      const float wn = tail_apply_pre(a, fi, (s0 + s1) + db0S[r] * beS[jj], ow, om, ov);
+      if (a.update && a.W0eP) a.W0eP[(size_t)w * a.TPe + j] = wn;
+    }
     return;
   }
   bid -= nA;
@@ -408,7 +414,10 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
 #pragma unroll
       for (int y = 0; y < 2; ++y) red[wv * 256 + (2 * jq + x) * 16 + 2 * iq + y] = acc[x][y];
     lds_barrier();
-    if (own) tail_apply_pre(a, fi, ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid], ow, om, ov);
+    if (own) {
+      const float wn = tail_apply_pre(a, fi, ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid], ow, om, ov);
+      if (a.update && a.WeP) a.WeP[(size_t)(j0 + jj) * a.TPe + i0 + ii] = wn;
+    }
     return;
   }
   // d emb_layer.bias[j] = sum_w W0e[w][j] * db0[w]: 16 columns per work-group, thread -> (column tid % 16, slice tid / 16 of the
