@@ -744,23 +744,9 @@ int launch_sk_step_nlnw(sdrm_engine* e, const SkStepArgs& ka, int which, int gri
     if (which == 0) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_bwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
-  static unsigned long long* g_st = nullptr; static int g_cnt = 0;   // TEMP diagnostic
-  SkStepArgs kb = ka;
-  if (std::getenv("SDRM_SK_STAMPS")) { if (!g_st) (void)hipMalloc((void**)&g_st, 16 * 8 * 1024); kb.stamps = g_st; }
-  if (which == 0) SDRM_LAUNCH(e, (k_skinny_fwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, kb);
-  else SDRM_LAUNCH(e, (k_skinny_bwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, kb);
+  if (which == 0) SDRM_LAUNCH(e, (k_skinny_fwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
+  else SDRM_LAUNCH(e, (k_skinny_bwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
   HIP_TRY(e, hipGetLastError());
-  if (kb.stamps && (++g_cnt == 40 || g_cnt == 41)) {
-    (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(16 * (size_t)std::min(grid, 1024));
-    (void)hipMemcpy(h.data(), g_st, h.size() * 8, hipMemcpyDeviceToHost);
-    for (int b = 0; b < (int)h.size() / 16; b += std::max(1, (int)h.size() / 16 / 6))
-    {
-      fprintf(stderr, "sk which %d wg %3d:", which, b);
-      for (int q = 1; q < 12; ++q) fprintf(stderr, " t%d %6lld", q, (long long)(h[16 * b + q] - h[16 * b]));
-      fprintf(stderr, "\n");
-    }
-  }
   return SDRM_OK;
 }
 
@@ -1524,25 +1510,12 @@ int backward_tail(sdrm_engine* e, float* gout, int which, bool update, float lr,
   a.Mred = e->Mred; a.snap = e->snap; a.WeP = e->WeP; a.W0eP = e->W0eP; a.TPe = e->TPe;
   a.b1 = 0.9f; a.b2 = 0.999f; a.eps = 1e-8f; a.wd = 1e-4f; a.update = update ? 1 : 0;
   if (update) adam_scalars(e, lr, a.step_size, a.bc2_sqrt);
-  static unsigned long long* g_tstamps = nullptr; static int g_tcount = 0;   // TEMP diagnostic
-  if (std::getenv("SDRM_TAIL_STAMPS")) { if (!g_tstamps) (void)hipMalloc((void**)&g_tstamps, 8 * 8 * 16384); a.stamps = g_tstamps; }
   int per_lane = 0;   // most slabs any lane of a weight job sums
   for (int q = 0; q < n; ++q)
     if (a.j[q].kind == TJ_MAT) per_lane = std::max(per_lane, (a.j[q].nslabs + a.j[q].lanes - 1) / a.j[q].lanes);
   if (per_lane <= 8) SDRM_LAUNCH(e, k_tail<8>, dim3((unsigned)blocks), dim3(TAIL_THREADS), 0, st, a);
   else SDRM_LAUNCH(e, k_tail<16>, dim3((unsigned)blocks), dim3(TAIL_THREADS), 0, st, a);
   HIP_TRY(e, hipGetLastError());
-  if (a.stamps && ++g_tcount == 30) {
-    (void)hipDeviceSynchronize();
-    std::vector<unsigned long long> h(8 * (size_t)std::min(blocks, 16384));
-    (void)hipMemcpy(h.data(), g_tstamps, h.size() * 8, hipMemcpyDeviceToHost);
-    unsigned long long r0min = ~0ull, r1max = 0;
-    for (int b = 0; b < (int)h.size() / 8; ++b) { r0min = std::min(r0min, h[8 * b + 7]); r1max = std::max(r1max, h[8 * b + 7]); }
-    fprintf(stderr, "tail: %d work-groups, starts spread over %llu x10ns\n", blocks, r1max - r0min);
-    for (int b = 0; b < (int)h.size() / 8; b += std::max(1, (int)h.size() / 8 / 24))
-      fprintf(stderr, "tail wg %5d kind %llu loads %6lld adam %6lld sync %6lld end %6lld  (start +%llu x10ns)\n", b, h[8 * b + 6],
-              (long long)(h[8 * b + 1] - h[8 * b]), (long long)(h[8 * b + 2] - h[8 * b]), (long long)(h[8 * b + 3] - h[8 * b]), (long long)(h[8 * b + 4] - h[8 * b]), h[8 * b + 7] - r0min);
-  }
   if (update) e->tables_fresh = false;
   if (which & BUCKET_FIRST) {
     const int eb = tail_emb_blocks_a(W, T) + tail_emb_blocks_b(T) + tail_emb_blocks_c(T);

@@ -54,9 +54,7 @@ struct SkStepArgs {
   float* slab0; float* slabH; float* slabO;        // [S][WPs][K0], [S][WPs][WPs], [S][LPs][WPs]: S = gridDim.x slab sets
   float* db0s; float* dbHs; float* dbOs;           // [S][WPs], [S][WPs], [S][LPs]
   float* alpha_part; int alpha_part_stride;        // [application][alpha_part_stride], entry = work-group
-  unsigned long long* stamps;                      // diagnostic runs only (SDRM_SK_STAMPS): 16 s_memtime slots per work-group
 };
-#define SK_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[16 * (size_t)blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <int NL, int NW>
 struct SkCfg {
@@ -128,8 +126,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
     }
     if (pass == 0 && ct < NW) b0c_ = a.b0[col];
   }
-
-  SK_STAMP(0);
   for (int g = blockIdx.x; g < a.G; g += gridDim.x) {
     const int u0 = SK_USERS * g;
     const size_t grow0 = (size_t)SK_ROWS * g;
@@ -167,7 +163,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
       trow[tid] = t0;
     }
     lds_barrier();
-    SK_STAMP(1);
     // layer 0's time-embedding term + bias: the table row of each accumulator row's timestep - in flight under the staging.
     // intab: the operands of E = temb[t_user] * We^T instead (wave w < TPe / 16 makes column tile w of it): the users' temb rows
     // as A fragments, the wave's rows of We as B fragments, all requested now
@@ -252,7 +247,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
       }
     }
     lds_barrier();
-    SK_STAMP(2);
     if (a.intab && ct < NW) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) b0v[r] = B0s[(4 * lq + r) * SCR + col];
@@ -302,7 +296,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
       }
     }
     lds_barrier();
-    SK_STAMP(3);
     // ---- loss partial sums (:196-198): R = P - x0, D = (Q - S) / mu^2 - R, over the group's users and the real columns
     {
       double sD = 0, sC = 0, sR = 0, sR2 = 0;
@@ -333,7 +326,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_fwd(con
       for (int w = 0; w < C::NWAVES; ++w) s += red[4 * w + tid];
       a.loss_part[4 * (size_t)g + tid] = s;
     }
-    SK_STAMP(4);
     lds_barrier();   // the next group's staging overwrites the tiles and trow
   }
 }
@@ -437,8 +429,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
   const float cV = (float)(-(0.5 * (A + Cc) / (den * den)) * 2.0 / (N - 1.0));
   const float rbar = (float)Rbar;
   if (s == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + Cc) / den);
-
-  SK_STAMP(0);
   f32x4 accH[TH];
   bool first = true;
   for (int g = blockIdx.x; g < a.G; g += gridDim.x, first = false) {
@@ -483,7 +473,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
         tereg[i] = in ? *reinterpret_cast<const float4*>(a.tembP + (size_t)a.tdev[u0 + ur] * a.TPs + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    SK_STAMP(1);
     // ---- seeds (App. A.5) times tanh' into Dt(0); zero the bias accumulators; act[H] into Xt(0)
 #pragma unroll
     for (int i = 0; i < NSEED; ++i) {
@@ -525,7 +514,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
       }
     }
     lds_barrier();
-    SK_STAMP(2);
     // ---- out layer: bias gradient = column sums of the seeds; weight gradient dWo[n < L][k < W] = seeds^T * act[H]
     for (int f = tid; f < 3 * C::LPk; f += NTHR) {
       const int p_ = f / C::LPk, c = f - p_ * C::LPk;
@@ -543,7 +531,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
     for (int i = 0; i < TH; ++i) accH[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // ---- the chain: iteration k produces dpre[k] (gradient of pre-activation k) from Dt(cur), then the weight gradient of the
     // layer whose OUTPUT is pre[k] (k >= 1: the shared hidden layer, input act[k-1]; k == 0: layer 0, input U)
-    SK_STAMP(3);
     int cur = 0, xc = 0;
     float ss_h = 0.f, ss_0 = 0.f, cs_h = 0.f, cs_0 = 0.f;
     // one iteration; (P0, P1, P2) = (pre[k], pre[k-1], pre[k-2]): P0 is this layer's PReLU', P1 the next layer input, P2 is requested
@@ -557,7 +544,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
 #pragma unroll
           for (int r = 0; r < 4; ++r) pv2[r] = pk[(grow0 + 16 * pass + 4 * lq + r) * a.WPs + col];
         }
-        if (k >= a.H - 1) SK_STAMP(6 + 3 * (a.H - k));
         f32x4 acc;
         if (k == a.H) {
           f32x4 af[NL];
@@ -591,9 +577,7 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
       }
       if (k == 0 && ct < NL)   // layer 0's input: the dropped-out latents the forward stored (requested at the top)
         *reinterpret_cast<f32x4*>(&Xt(xc ^ 1)[(16 * pass + (lane >> 2)) * SCR + ct * 16 + 4 * (lane & 3)]) = ureg;
-      if (k >= a.H - 1) SK_STAMP(7 + 3 * (a.H - k));
       lds_barrier();
-      if (k >= a.H - 1) SK_STAMP(8 + 3 * (a.H - k));
       if (k >= 1) {
         for (int i = 0; i < TH; ++i) {
           const int tl = wave + i * NWAVES;
@@ -637,7 +621,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
       if (lane == 0) { red[0 * 12 + wave] = ct < NW ? s0_ : 0.f; red[1 * 12 + wave] = ct < NW ? sh_ : 0.f; }
     }
     lds_barrier();
-    SK_STAMP(4);
     // ---- M[n < W][i < T] = sum over the group's users of D3[u][n] * temb[t_u][i], into the trailing columns of the layer-0 slab
     {
       const int TT = a.TPs / 16;
@@ -668,7 +651,6 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
       float* dst = a.alpha_part + (size_t)tid * a.alpha_part_stride + s;
       if (first) *dst = sum; else *dst += sum;
     }
-    SK_STAMP(5);
   }
 }
 

@@ -67,9 +67,7 @@ struct TailArgs {
   float* WeP; float* W0eP; int TPe;
   float step_size, bc2_sqrt, b1, b2, eps, wd;
   int update;
-  unsigned long long* stamps;   // diagnostic runs only (SDRM_TAIL_STAMPS): 8 slots per work-group of k_tail
 };
-#define TSTAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[8 * (size_t)blockIdx.x + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // Adam on an element whose state was loaded up front: g -> flat gradient, (w, m, v) -> p, m, v; returns the (new) value
 __device__ __forceinline__ float tail_apply_pre(const TailArgs& a, int64_t fi, float g, float w, float m, float v) {
@@ -154,7 +152,6 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
   if (LANES >= 2) { g4.x += __shfl_xor(g4.x, 1, 64); g4.y += __shfl_xor(g4.y, 1, 64); g4.z += __shfl_xor(g4.z, 1, 64); g4.w += __shfl_xor(g4.w, 1, 64); }
   if (LANES == 4) { g4.x += __shfl_xor(g4.x, 2, 64); g4.y += __shfl_xor(g4.y, 2, 64); g4.z += __shfl_xor(g4.z, 2, 64); g4.w += __shfl_xor(g4.w, 2, 64); }
   const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-  TSTAMP(1);
   if (reduce_only) {
 #pragma unroll
     for (int e = 0; e < NE; ++e)
@@ -164,7 +161,6 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
 #pragma unroll
   for (int e = 0; e < NE; ++e)
     if (ok[e]) w[e] = tail_apply_pre(a, jb.flat_off + (int64_t)R * jb.flat_ld + Cq + part * NE + e, gv[part * NE + e], w[e], m[e], v[e]);
-  TSTAMP(2);
   if (!a.update) return;
   // the padded copy: a thread's quad (LANES = 1) or the lanes of the quad together are 16 consecutive bytes, a row of the tile 64 / 128
   if (jb.dst) {
@@ -179,7 +175,6 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
 #pragma unroll
   for (int e = 0; e < NE; ++e) tile[pr][4 * pq + part * NE + e] = w[e];
   lds_barrier();   // (not __syncthreads: that would wait for the p / m / v / g stores above)
-  TSTAMP(3);
   // the other copies out of the LDS image (only the entries of real elements: their padding stays as sdrm_create left it)
   for (int f = tid; f < TSR * TSC; f += TAIL_THREADS) {
     if (jb.dstT) {   // [c][r]: consecutive threads -> consecutive rows of one column
@@ -212,14 +207,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
     if (q < a.n && (int)blockIdx.x >= a.start[q]) k = q;
   const TailJob& jb = a.j[k];
   const int bid = (int)blockIdx.x - a.start[k];
-  TSTAMP(0);
-  if (a.stamps && tid == 0) { a.stamps[8 * (size_t)blockIdx.x + 6] = jb.kind; a.stamps[8 * (size_t)blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime(); }
 
   if (jb.kind == TJ_MAT) {
     if (jb.lanes == 4) tail_mat<4, BATCH>(a, jb, bid, tsh);
     else if (jb.lanes == 2) tail_mat<2, BATCH>(a, jb, bid, tsh);
     else tail_mat<1, BATCH>(a, jb, bid, tsh);
-    TSTAMP(4);
     return;
   }
 
