@@ -113,27 +113,9 @@ __device__ __forceinline__ float dot_quad(const float* __restrict__ x, int sx, c
   return s;
 }
 
-__device__ __forceinline__ void emb_tables_row(const EmbTabArgs& a, int t, float* sh /* [2*T] */) {
-  float* tr = sh;
-  float* er = sh + a.T;
-  for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
-  __syncthreads();
-  for (int j = threadIdx.x; j < a.T; j += blockDim.x) {
-    const float s = a.be[j] + dot_unrolled(a.We + (size_t)j * a.T, tr, a.T);
-    er[j] = s;
-  }
-  __syncthreads();
-  const int ldw = a.L + a.T;
-  for (int w = threadIdx.x; w < a.WP; w += blockDim.x) {
-    const float s = (w < a.W) ? dot_unrolled(a.W0 + (size_t)w * ldw + a.L, er, a.T) : 0.f;
-    a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
-    if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : (w == a.ones_col ? 1.f : 0.f);
-  }
-}
-
 // The same row with FOUR lanes per output (1024 threads): a dot product's loads are all in flight at once - one memory round
 // trip per phase instead of five.  The stand-alone launch sits on the critical path in front of the row-owned forward
-// (10.5 -> 5 us at ML-1M); k_prep_train's leading blocks keep the 256-thread form (hidden beside the staging blocks).
+// (10.5 -> 5 us at ML-1M).
 __device__ __forceinline__ void emb_tables_row4(const EmbTabArgs& a, int t, float* sh /* [2*T] */) {
   float* tr = sh;
   float* er = sh + a.T;
@@ -147,6 +129,32 @@ __device__ __forceinline__ void emb_tables_row4(const EmbTabArgs& a, int t, floa
   __syncthreads();
   const int ldw = a.L + a.T;
   for (int w = q; w < a.WP; w += nq) {
+    const float s = (w < a.W) ? dot_quad<20>(a.W0 + (size_t)w * ldw + a.L, 1, er, 1, a.T, l4) : 0.f;
+    if (l4 == 0) {
+      a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
+      if (a.B0tab) a.B0tab[(size_t)t * a.WP + w] = (w < a.W) ? s + a.b0[w] : (w == a.ones_col ? 1.f : 0.f);
+    }
+  }
+}
+
+// One row t of the tables for the 64 output columns of chunk `wc` only, on a 256-thread block (64 quads of lanes): the E row is
+// made again by every chunk's block (two round trips), its 64 columns of C0 are one more - k_prep_train's leading blocks, which
+// were a chain of fifteen round trips (10 us, the launch's long pole) when one block of single lanes made a whole row.  Same
+// arithmetic, lane for lane, as emb_tables_row4.
+__device__ __forceinline__ void emb_tables_chunk(const EmbTabArgs& a, int t, int wc, float* sh /* [2*T] */) {
+  float* tr = sh;
+  float* er = sh + a.T;
+  for (int i = threadIdx.x; i < a.T; i += blockDim.x) tr[i] = a.temb[(size_t)t * a.T + i];
+  __syncthreads();
+  const int q = threadIdx.x >> 2, l4 = threadIdx.x & 3, nq = blockDim.x >> 2;
+  for (int j = q; j < a.T; j += nq) {
+    const float s = a.be[j] + dot_quad<20>(a.We + (size_t)j * a.T, 1, tr, 1, a.T, l4);
+    if (l4 == 0) er[j] = s;
+  }
+  __syncthreads();
+  const int ldw = a.L + a.T;
+  const int w = nq * wc + q;
+  if (w < a.WP) {
     const float s = (w < a.W) ? dot_quad<20>(a.W0 + (size_t)w * ldw + a.L, 1, er, 1, a.T, l4) : 0.f;
     if (l4 == 0) {
       a.W0c[(size_t)w * a.K0 + a.LP + t] = s;
@@ -191,13 +199,14 @@ struct PrepTrainArgs {
   int B, L, LP, K0, T, MP;
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
   EmbTabArgs emb; int emb_row0;   // staged + zero-pad rows; the first `emb_blocks` blocks build the step's embedding
-  int emb_blocks;                 // tables (independent work, merged here so it runs beside the staging)
+  int emb_blocks, emb_chunks;     // tables (independent work, merged here so it runs beside the staging): (T + 1) rows x chunks of 64 columns
 };
 
 __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
   extern __shared__ float sh[];
-  if ((int)blockIdx.x < a.emb_blocks) {   // leading blocks (dispatched first: each is a ~10 us serial chain, the
-    emb_tables_row(a.emb, (int)blockIdx.x, sh);   // staging blocks behind them fill the rest of the chip meanwhile)
+  if ((int)blockIdx.x < a.emb_blocks) {   // leading blocks (dispatched first; the staging blocks behind them fill the rest of
+    const int t = (int)blockIdx.x / a.emb_chunks;   // the chip meanwhile): row t of the tables, 64 output columns each
+    emb_tables_chunk(a.emb, t, (int)blockIdx.x - t * a.emb_chunks, sh);
     return;
   }
   // one thread per group of four columns of one staged row triple (16-byte stores; the row's t is drawn once

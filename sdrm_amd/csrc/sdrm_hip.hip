@@ -1245,7 +1245,8 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     pa.emb = emb_args(e);
     e->tables_fresh = true;
     pa.emb_row0 = B + (MP - 3 * B);
-    pa.emb_blocks = e->T + 1;
+    pa.emb_chunks = (e->WP + 63) / 64;
+    pa.emb_blocks = (e->T + 1) * pa.emb_chunks;
     const int main_blocks = (int)(((int64_t)pa.emb_row0 * (e->K0 / 4) + 255) / 256);
     SDRM_LAUNCH(e, k_prep_train, dim3(pa.emb_blocks + main_blocks), dim3(256), 2 * e->T * sizeof(float), st, pa);
     HIP_TRY(e, hipGetLastError());

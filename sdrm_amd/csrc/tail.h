@@ -272,13 +272,13 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
 // ---- second launch: the embedding path.  Work-groups [0, nA): 8 rows x 32 columns of W0e; [nA, nA + nB): 16 x 16 tiles of
 // emb_layer.weight; then 16 entries of emb_layer.bias each.
 constexpr int TE_RB = 8, TE_JT = 32;     // W0e work-groups: rows, columns
-constexpr int TE_WT = 16, TE_WC = 128;   // emb_layer.weight work-groups: tile edge, rows of the contraction per chunk
+constexpr int TE_WT = 16, TE_WC = 256;   // emb_layer.weight work-groups: tile edge, rows of the contraction per chunk
 __host__ __device__ inline int tail_emb_blocks_a(int W, int T) { return ((W + TE_RB - 1) / TE_RB) * ((T + TE_JT - 1) / TE_JT); }
 __host__ __device__ inline int tail_emb_blocks_b(int T) { return ((T + TE_WT - 1) / TE_WT) * ((T + TE_WT - 1) / TE_WT); }
 __host__ __device__ inline int tail_emb_blocks_c(int T) { return (T + 15) / 16; }
 __host__ __device__ inline size_t tail_emb_lds_floats(int T, int TP) {
   const size_t a_ = (size_t)TE_JT * (T + 1) + (size_t)TE_RB * TP + TE_RB + TE_JT;
-  const size_t b_ = (size_t)2 * 2 * TE_WC * (TE_WT + 2);
+  const size_t b_ = (size_t)2 * TE_WC * (TE_WT + 2);
   return (a_ > b_ ? a_ : b_) + 8;
 }
 
@@ -355,8 +355,9 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
   }
   bid -= nA;
   if (bid < nB) {
-    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: a 16 x 16 tile per work-group; the contraction in chunks of 128 rows
-    // through LDS (the next chunk's loads in flight while this one is multiplied).  Wave v takes rows v, v + 4, .. of a chunk for
+    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: a 16 x 16 tile per work-group; the contraction in chunks of 256 rows
+    // through LDS (the next chunk's loads in flight while this one is multiplied: a chunk is one memory round trip, and with
+    // 128-row chunks the seven of W = 830 were this launch's long pole).  Wave v takes rows v, v + 4, .. of a chunk for
     // ALL 256 outputs, 2 x 2 of them per lane (two 8-byte LDS reads per four multiply-adds); the four waves' sums meet in LDS.
     const int nt = (T + TE_WT - 1) / TE_WT;
     const int j0 = (bid / nt) * TE_WT, i0 = (bid % nt) * TE_WT;
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
     const int wv = tid >> 6, ln = tid & 63, jq = ln >> 3, iq = ln & 7;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     load(0);
-    int buf = 0;
-    for (int wc0 = 0; wc0 < a.W; wc0 += TE_WC, buf ^= 1) {
-      float* As = esh + buf * 2 * TE_WC * LDT;
-      float* Bs = As + TE_WC * LDT;
+    float* As = esh;
+    float* Bs = As + TE_WC * LDT;
+    for (int wc0 = 0; wc0 < a.W; wc0 += TE_WC) {
+      if (wc0 > 0) lds_barrier();   // every wave is done with the previous chunk
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = u * 256 + tid;
@@ -389,8 +390,7 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
         Bs[(f >> 4) * LDT + (f & 15)] = xb[u];
       }
       if (wc0 + TE_WC < a.W) load(wc0 + TE_WC);
-      lds_barrier();     // (LDS only: the next chunk's loads stay in flight; two LDS buffers: the chunk written now was last read two
-                         // iterations ago, behind the barrier in between)
+      lds_barrier();     // (LDS only: the next chunk's loads stay in flight)
 #pragma unroll 8
       for (int q = wv; q < TE_WC; q += 4) {
         const float2 av = *reinterpret_cast<const float2*>(As + q * LDT + 2 * jq);
