@@ -134,17 +134,22 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
   const int R = r0 + pr, Cq = c0 + 4 * pq;
   const bool rok = R < jb.rows;
   const bool reduce_only = jb.red != nullptr;
-  // everything this thread will need, requested at once
+  // Two thread -> element mappings.  The slab pieces are 16-byte loads: thread -> (row, column quad, part).  The flat vectors
+  // p / m / v / g have rows of flat_ld floats (not 16-byte aligned in general), so there the NE elements of a thread are element
+  // tid + 256 u of the sub-tile, row-major: a wave instruction touches whole 64- / 128-byte runs (with the quad mapping every
+  // instruction touched a quarter of each line it asked for, four instructions per line: the 830-wide net's tail ran at 2.7 TB/s).
+  // The sums change mapping through the LDS tile.  Everything this thread will need is requested at once:
   float w[NE], m[NE], v[NE];
   bool ok[NE];
+  int64_t fi[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int C = Cq + part * NE + e;
-    ok[e] = rok && C < jb.cols;
-    const int64_t fi = jb.flat_off + (int64_t)R * jb.flat_ld + C;
-    w[e] = (ok[e] && !reduce_only) ? a.p[fi] : 0.f;
-    m[e] = (ok[e] && !reduce_only && a.update) ? a.m[fi] : 0.f;
-    v[e] = (ok[e] && !reduce_only && a.update) ? a.v[fi] : 0.f;
+  for (int u = 0; u < NE; ++u) {
+    const int f = tid + TAIL_THREADS * u, rr = f / TSC, cc = f % TSC;
+    ok[u] = !reduce_only && r0 + rr < jb.rows && c0 + cc < jb.cols;
+    fi[u] = jb.flat_off + (int64_t)(r0 + rr) * jb.flat_ld + c0 + cc;
+    w[u] = ok[u] ? a.p[fi[u]] : 0.f;
+    m[u] = (ok[u] && a.update) ? a.m[fi[u]] : 0.f;
+    v[u] = (ok[u] && a.update) ? a.v[fi[u]] : 0.f;
   }
   const int kb = (jb.nslabs * part) / LANES, ke = (jb.nslabs * (part + 1)) / LANES;
   // (rows beyond the matrix: the loads go to row 0 and are not used - a tile may reach past the slab's padded rows)
@@ -155,25 +160,23 @@ __device__ __forceinline__ void tail_mat(const TailArgs& a, const TailJob& jb, i
   if (reduce_only) {
 #pragma unroll
     for (int e = 0; e < NE; ++e)
-      if (ok[e]) jb.red[(size_t)R * jb.red_ld + Cq + part * NE + e] = gv[part * NE + e];
+      if (rok && Cq + part * NE + e < jb.cols) jb.red[(size_t)R * jb.red_ld + Cq + part * NE + e] = gv[part * NE + e];
     return;
   }
 #pragma unroll
-  for (int e = 0; e < NE; ++e)
-    if (ok[e]) w[e] = tail_apply_pre(a, jb.flat_off + (int64_t)R * jb.flat_ld + Cq + part * NE + e, gv[part * NE + e], w[e], m[e], v[e]);
-  if (!a.update) return;
-  // the padded copy: a thread's quad (LANES = 1) or the lanes of the quad together are 16 consecutive bytes, a row of the tile 64 / 128
-  if (jb.dst) {
-    if (LANES == 1 && ok[3]) *reinterpret_cast<float4*>(jb.dst + (size_t)R * jb.dst_ld + Cq) = make_float4(w[0], w[1], w[2], w[3]);
-    else {
+  for (int e = 0; e < NE; ++e) tile[pr][4 * pq + part * NE + e] = gv[part * NE + e];
+  lds_barrier();
 #pragma unroll
-      for (int e = 0; e < NE; ++e)
-        if (ok[e]) jb.dst[(size_t)R * jb.dst_ld + Cq + part * NE + e] = w[e];
+  for (int u = 0; u < NE; ++u) {
+    const int f = tid + TAIL_THREADS * u, rr = f / TSC, cc = f % TSC;
+    if (ok[u]) {
+      w[u] = tail_apply_pre(a, fi[u], tile[rr][cc], w[u], m[u], v[u]);
+      if (a.update && jb.dst) jb.dst[(size_t)(r0 + rr) * jb.dst_ld + c0 + cc] = w[u];   // the padded copy, whole rows of the sub-tile
     }
+    tile[rr][cc] = w[u];   // (the entry this thread has just read: no other thread touches it before the barrier below)
   }
+  if (!a.update) return;
   if (jb.dstT == nullptr && jb.dstF == nullptr && jb.dstFT == nullptr) return;
-#pragma unroll
-  for (int e = 0; e < NE; ++e) tile[pr][4 * pq + part * NE + e] = w[e];
   lds_barrier();   // (not __syncthreads: that would wait for the p / m / v / g stores above)
   // the other copies out of the LDS image (only the entries of real elements: their padding stays as sdrm_create left it)
   for (int f = tid; f < TSR * TSC; f += TAIL_THREADS) {
