@@ -272,15 +272,15 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail(const TailArgs a) {
   if (tid == 0) tail_apply_pre(a, jb.flat_off, (tsh[0] + tsh[1]) + (tsh[2] + tsh[3]), w0, m0, v0);
 }
 
-// ---- second launch: the embedding path.  Work-groups [0, nA): 8 rows x 32 columns of W0e; [nA, nA + nB): 16 x 16 tiles of
+// ---- second launch: the embedding path.  Work-groups [0, nA): 8 rows x 32 columns of W0e; [nA, nA + nB): 8 x 8 tiles of
 // emb_layer.weight; then 16 entries of emb_layer.bias each.
 constexpr int TE_RB = 8, TE_JT = 32;     // W0e work-groups: rows, columns
-constexpr int TE_WT = 16, TE_WC = 256;   // emb_layer.weight work-groups: tile edge, rows of the contraction per chunk
+constexpr int TE_WT = 8, TE_WC = 256;    // emb_layer.weight work-groups: tile edge, rows of the contraction per chunk
 __host__ __device__ inline int tail_emb_blocks_a(int W, int T) { return ((W + TE_RB - 1) / TE_RB) * ((T + TE_JT - 1) / TE_JT); }
 __host__ __device__ inline int tail_emb_blocks_b(int T) { return ((T + TE_WT - 1) / TE_WT) * ((T + TE_WT - 1) / TE_WT); }
 __host__ __device__ inline int tail_emb_blocks_c(int T) { return (T + 15) / 16; }
 __host__ __device__ inline size_t tail_emb_lds_floats(int T, int TP) {
-  const size_t a_ = (size_t)TE_JT * (T + 1) + (size_t)TE_RB * TP + TE_RB + TE_JT;
+  const size_t a_ = (size_t)TE_JT * (T + 2) + (size_t)TE_RB * TP + TE_RB + TE_JT;
   const size_t b_ = (size_t)2 * TE_WC * (TE_WT + 2);
   return (a_ > b_ ? a_ : b_) + 8;
 }
@@ -299,8 +299,9 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
     const int ntj = (T + TE_JT - 1) / TE_JT;
     const int w0 = (bid / ntj) * TE_RB, j0 = (bid % ntj) * TE_JT;
     float* Ms = esh;                                  // [8][TP] (16-byte rows)
-    float* WeS = Ms + TE_RB * TP;                     // [32][T + 1]
-    float* db0S = WeS + TE_JT * (T + 1);              // [8]
+    const int ldws = (T + 1) | 1;                     // odd: the 32 lanes of a row read 32 different banks
+    float* WeS = Ms + TE_RB * TP;                     // [32][ldws]
+    float* db0S = WeS + TE_JT * ldws;                 // [8]
     float* beS = db0S + TE_RB;                        // [32]
     const int r = tid >> 5, jj = tid & 31;
     const int w = w0 + r, j = j0 + jj;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int jr = wv + 4 * rr, i = i0 + ln + 64 * h;
-            if (i < T) WeS[jr * (T + 1) + i] = vv[rr][h];
+            if (i < T) WeS[jr * ldws + i] = vv[rr][h];
           }
       }
     }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
     __syncthreads();
     float s0 = 0.f, s1 = 0.f;
     const float* mr = Ms + r * TP;
-    const float* wr = WeS + jj * (T + 1);
+    const float* wr = WeS + jj * ldws;
     int i = 0;
     for (; i + 1 < T; i += 2) { s0 = fmaf(mr[i], wr[i], s0); s1 = fmaf(mr[i + 1], wr[i + 1], s1); }
     if (i < T) s0 = fmaf(mr[i], wr[i], s0);
@@ -358,28 +359,29 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
   }
   bid -= nA;
   if (bid < nB) {
-    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: a 16 x 16 tile per work-group; the contraction in chunks of 256 rows
-    // through LDS (the next chunk's loads in flight while this one is multiplied: a chunk is one memory round trip, and with
-    // 128-row chunks the seven of W = 830 were this launch's long pole).  Wave v takes rows v, v + 4, .. of a chunk for
-    // ALL 256 outputs, 2 x 2 of them per lane (two 8-byte LDS reads per four multiply-adds); the four waves' sums meet in LDS.
+    // d emb_layer.weight[j][i] = sum_w W0e[w][j] * M[w][i]: an 8 x 8 tile per work-group (what a work-group costs is the bytes it
+    // pulls, W x (8 + 8) floats: with 16 x 16 tiles the 106 KB of W = 830 were 14 us, the whole launch); the contraction in
+    // chunks of 256 rows through LDS (the next chunk's loads in flight while this one is multiplied).  Sixteen groups of 16 lanes
+    // take rows g, g + 16, .. of a chunk for ALL 64 outputs, 2 x 2 of them per lane (two 8-byte LDS reads per four
+    // multiply-adds); the groups' sums meet in LDS, in a fixed order.
     const int nt = (T + TE_WT - 1) / TE_WT;
     const int j0 = (bid / nt) * TE_WT, i0 = (bid % nt) * TE_WT;
-    const int jj = tid >> 4, ii = tid & 15;                 // this thread's OUTPUT (after the waves' sums have met)
-    const bool own = j0 + jj < T && i0 + ii < T;
+    const int jj = (tid >> 3) & 7, ii = tid & 7;            // thread tid < 64: its OUTPUT (after the groups' sums have met)
+    const bool own = tid < TE_WT * TE_WT && j0 + jj < T && i0 + ii < T;
     const int64_t fi = a.off_we + (int64_t)(own ? j0 + jj : 0) * T + (own ? i0 + ii : 0);
-    const float ow = a.p[fi], om = a.update ? a.m[fi] : 0.f, ov = a.update ? a.v[fi] : 0.f;
-    constexpr int PER = TE_WC * TE_WT / 256;   // 8 floats of each operand per thread and chunk: (row f / 16, column f % 16)
-    constexpr int LDT = TE_WT + 2;             // LDS row stride: even (8-byte reads), 18 floats
+    const float ow = own ? a.p[fi] : 0.f, om = (own && a.update) ? a.m[fi] : 0.f, ov = (own && a.update) ? a.v[fi] : 0.f;
+    constexpr int PER = TE_WC * TE_WT / 256;   // 8 floats of each operand per thread and chunk: (row f / 8, column f % 8)
+    constexpr int LDT = TE_WT + 2;             // LDS row stride: even (8-byte reads), 10 floats
     float xa[PER], xb[PER];
     auto load = [&](int wc0) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        const int f = u * 256 + tid, wr_ = wc0 + (f >> 4), cc = f & 15;
+        const int f = u * 256 + tid, wr_ = wc0 + (f >> 3), cc = f & 7;
         xa[u] = (wr_ < a.W && j0 + cc < T) ? snapW0e[(size_t)wr_ * T + j0 + cc] : 0.f;
         xb[u] = (wr_ < a.W && i0 + cc < T) ? a.Mred[(size_t)wr_ * TP + i0 + cc] : 0.f;
       }
     };
-    const int wv = tid >> 6, ln = tid & 63, jq = ln >> 3, iq = ln & 7;
+    const int grp = tid >> 4, jq = (tid >> 2) & 3, iq = tid & 3;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     load(0);
     float* As = esh;
@@ -389,28 +391,31 @@ __global__ __launch_bounds__(256) void k_tail_emb(const TailArgs a) {
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
         const int f = u * 256 + tid;
-        As[(f >> 4) * LDT + (f & 15)] = xa[u];
-        Bs[(f >> 4) * LDT + (f & 15)] = xb[u];
+        As[(f >> 3) * LDT + (f & 7)] = xa[u];
+        Bs[(f >> 3) * LDT + (f & 7)] = xb[u];
       }
       if (wc0 + TE_WC < a.W) load(wc0 + TE_WC);
       lds_barrier();     // (LDS only: the next chunk's loads stay in flight)
 #pragma unroll 8
-      for (int q = wv; q < TE_WC; q += 4) {
+      for (int q = grp; q < TE_WC; q += 16) {
         const float2 av = *reinterpret_cast<const float2*>(As + q * LDT + 2 * jq);
         const float2 bv = *reinterpret_cast<const float2*>(Bs + q * LDT + 2 * iq);
         acc[0][0] = fmaf(av.x, bv.x, acc[0][0]); acc[0][1] = fmaf(av.x, bv.y, acc[0][1]);
         acc[1][0] = fmaf(av.y, bv.x, acc[1][0]); acc[1][1] = fmaf(av.y, bv.y, acc[1][1]);
       }
     }
-    lds_barrier();   // every wave is done with the operand buffers: they become the waves' partial sums [4][16][16]
+    lds_barrier();   // every wave is done with the operand buffers: they become the groups' partial sums [16][8][8]
     float* red = esh;
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int y = 0; y < 2; ++y) red[wv * 256 + (2 * jq + x) * 16 + 2 * iq + y] = acc[x][y];
+      for (int y = 0; y < 2; ++y) red[grp * 64 + (2 * jq + x) * 8 + 2 * iq + y] = acc[x][y];
     lds_barrier();
     if (own) {
-      const float wn = tail_apply_pre(a, fi, ((red[tid] + red[256 + tid]) + red[512 + tid]) + red[768 + tid], ow, om, ov);
+      float s4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s4[k] = (red[(4 * k) * 64 + tid] + red[(4 * k + 1) * 64 + tid]) + (red[(4 * k + 2) * 64 + tid] + red[(4 * k + 3) * 64 + tid]);
+      const float wn = tail_apply_pre(a, fi, (s4[0] + s4[1]) + (s4[2] + s4[3]), ow, om, ov);
       if (a.update && a.WeP) a.WeP[(size_t)(j0 + jj) * a.TPe + i0 + ii] = wn;
     }
     return;
