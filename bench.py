@@ -384,7 +384,7 @@ def main():
     # launcher (sdrm_amd/launch.py), relay rank 0's line (the children inherit stdout) and its exit code.
     from sdrm_amd import launch
     if args.gpus > 1 and not launch.inside_launcher():
-        sys.exit(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+        sys.exit(launch.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, stdout=REAL_STDOUT))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -617,10 +617,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(REAL_STDOUT, (json.dumps(out) + "\n").encode())   # the ONE line of this command's stdout
     if world > 1:
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
+    # stdout carries the JSON line and nothing else: libraries that print from C (RCCL's version banner at communicator
+    # creation goes to fd 1) are sent to stderr for the life of the process; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     main()

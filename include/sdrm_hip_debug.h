@@ -31,7 +31,7 @@ int sdrm_debug_set_tile(sdrm_engine* e, int cfg);
  * that threshold alone.  Also env SDRM_NT32_MAX_ROWS / SDRM_NT32_MAX_ROWS_TRAIN. */
 int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train);
 /* Enables (default) / disables the LDS-resident kernels used when the padded widths are <= 64 (csrc/skinny.h,
- * csrc/skinny_train.h); with them off, narrow nets go through the general per-layer GEMM path. */
+ * csrc/skinny_step.h); with them off, narrow nets go through the general per-layer GEMM path. */
 int sdrm_debug_set_skinny(sdrm_engine* e, int on);
 /* Row-owned train forward (csrc/rowchain.h: staging, every layer and the loss partial sums of a 96-row group of stacked rows in
  * ONE work-group per CU; nets with L == W and a padded width of 128..352): 0 never, 1 (default) when the batch fills whole

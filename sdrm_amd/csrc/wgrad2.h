@@ -12,7 +12,7 @@
 // on load.  Bias gradients: the operand carries a column of ones (pad column `ones_col` of U / act), so column ones_col of
 // every slab IS the bias gradient - no column sums in the loop.
 //
-// Slabs: [slice][n][k] per problem, reduced in fixed order by k_grad_finalize (deterministic).
+// Slabs: [slice][n][k] per problem, reduced in fixed order by k_tail (csrc/tail.h; deterministic).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -28,8 +28,9 @@ def rank_command(script: str, argv, nprocs: int, port: int):
             "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script, *argv]
 
 
-def launch_ranks(script: str, argv, nprocs: int, env=None, timeout=None) -> int:
-    """Runs `script argv` as `nprocs` ranks; returns the launcher's exit code (non-zero if any rank failed)."""
+def launch_ranks(script: str, argv, nprocs: int, env=None, timeout=None, stdout=None) -> int:
+    """Runs `script argv` as `nprocs` ranks; returns the launcher's exit code (non-zero if any rank failed).  `stdout`: the file
+    descriptor the ranks inherit as their stdout (default: this process's)."""
     if nprocs < 1:
         raise ValueError("nprocs must be >= 1")
     e = dict(os.environ if env is None else env)
@@ -37,7 +38,7 @@ def launch_ranks(script: str, argv, nprocs: int, env=None, timeout=None) -> int:
     e.setdefault("MASTER_ADDR", "127.0.0.1")
     cmd = rank_command(script, list(argv), nprocs, free_port())
     try:
-        return subprocess.run(cmd, env=e, timeout=timeout).returncode
+        return subprocess.run(cmd, env=e, timeout=timeout, stdout=stdout).returncode
     except subprocess.TimeoutExpired:
         print(f"launch_ranks: {nprocs} ranks of {os.path.basename(script)} did not finish within {timeout} s", file=sys.stderr)
         return 124
