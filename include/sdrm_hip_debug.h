@@ -30,8 +30,9 @@ int sdrm_debug_set_tile(sdrm_engine* e, int cfg);
  * 4096) / max_rows_train stacked rows (train step; default 8192) run on the 32x32x32 tile.  A negative value leaves
  * that threshold alone.  Also env SDRM_NT32_MAX_ROWS / SDRM_NT32_MAX_ROWS_TRAIN. */
 int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train);
-/* Enables (default) / disables the LDS-resident kernels used when the padded widths are <= 64 (csrc/skinny.h,
- * csrc/skinny_step.h); with them off, narrow nets go through the general per-layer GEMM path. */
+/* The LDS-resident kernels used when the padded widths are <= 64 (csrc/skinny.h, csrc/skinny_step.h, csrc/skinny_fwd4.h):
+ * 1 (default) on, the train forward owning 4 users per work-group (4x4x1 MFMAs); 2 on, with the 16-user train forward (what shapes
+ * whose LDS image does not fit take anyway); 0 off: narrow nets go through the general per-layer GEMM path. */
 int sdrm_debug_set_skinny(sdrm_engine* e, int on);
 /* Row-owned train forward (csrc/rowchain.h: staging, every layer and the loss partial sums of a 96-row group of stacked rows in
  * ONE work-group per CU; nets with L == W and a padded width of 128..352): 0 never, 1 (default) when the batch fills whole

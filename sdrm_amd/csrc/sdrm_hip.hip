@@ -22,6 +22,7 @@
 #include "select.h"
 #include "skinny.h"
 #include "skinny_step.h"
+#include "skinny_fwd4.h"
 #include "tail.h"
 #include "dgrad_rows.h"
 #include "wgrad2.h"
@@ -47,7 +48,7 @@ struct Tuning {
   int chains = -1;               // SDRM_CHAINS: sampler row chains, -1 = by size, 1..4 forced
   int fuse_rev = 1;              // SDRM_FUSE_REV: reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX
                                  // sampling): 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always
-  int skinny = 1;                // LDS-resident kernels for nets with padded widths <= 64 (persistent sampler, fused train
+  int skinny = 1;                // (2: with the 16-user train forward instead of the 4-user one) LDS-resident kernels for nets with padded widths <= 64 (persistent sampler, fused train
                                  // forward and dgrad chain)
   int nt32_max_rows = 4096;      // SDRM_NT32_MAX_ROWS: sampling / plain-forward NT launches of at most this many rows use the 32x32 tile
   int nt32_max_rows_train = 8192;  // SDRM_NT32_MAX_ROWS_TRAIN: the same for the train step's launches (stacked rows = 3 x batch):
@@ -80,6 +81,7 @@ struct sdrm_engine {
                                                           // (layer 0: the latent columns only); null when the net does not qualify
   bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
   bool cur_sk = false;               // ... grouped by 16 users (the narrow nets' step, csrc/skinny_step.h)
+  int cur_sk_np = 0;                 // ... and the loss partials its forward left (G, or 4 G: csrc/skinny_fwd4.h)
   bool tables_fresh = false;         // B0tab / the C0^T columns of W0c belong to the current parameters
   float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
                                      // the weight gradients of that step read their operand without PReLU on load
@@ -730,7 +732,7 @@ SkStepArgs sk_step_args(sdrm_engine* e, int B) {
   a.B = B; a.L = e->L; a.W = e->W; a.T = e->T; a.H = e->H; a.G = (B + SK_USERS - 1) / SK_USERS;
   a.LPs = e->LP; a.WPs = e->WP; a.TPs = e->TP;
   a.U = e->U; a.tdev = e->tdev; a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.Y = e->Y;
-  a.loss_part = e->loss_part;
+  a.loss_part = e->loss_part; a.NP = a.G;
   a.slab0 = e->slab0; a.slabH = e->slabH; a.slabO = e->slabO; a.db0s = e->db0s; a.dbHs = e->dbHs; a.dbOs = e->dbOs;
   a.alpha_part = e->alpha_part; a.alpha_part_stride = e->alpha_part_stride;
   return a;
@@ -748,6 +750,38 @@ int launch_sk_step_nlnw(sdrm_engine* e, const SkStepArgs& ka, int which, int gri
   else SDRM_LAUNCH(e, (k_skinny_bwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
+}
+
+// the narrow nets' forward on 4-row MFMA units (csrc/skinny_fwd4.h): one work-group per 4 users; false: the shape's LDS image does
+// not fit (the caller takes k_skinny_fwd)
+template <int NL, int NW>
+int launch_sk_fwd4_nlnw(sdrm_engine* e, const SkStepArgs& ka, hipStream_t st, bool* done) {
+  const size_t lds = sk4_fwd_lds_floats<NL, NW>(ka.intab ? ka.TPe : 0) * sizeof(float);
+  *done = false;
+  if (lds > 160 * 1024) return SDRM_OK;
+  if (lds > 48 * 1024) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd4<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SDRM_LAUNCH(e, (k_skinny_fwd4<NL, NW>), dim3((unsigned)std::min(ka.NP, 8192)), dim3(SK4_THREADS), lds, st, ka);
+  HIP_TRY(e, hipGetLastError());
+  *done = true;
+  return SDRM_OK;
+}
+
+int launch_sk_fwd4(sdrm_engine* e, const SkStepArgs& ka, hipStream_t st, bool* done) {
+  const int NL = (e->L + 15) / 16, NW = (e->W + 15) / 16;
+#define SK4_ROW(nl)                                                           \
+  switch (NW) {                                                               \
+    case 1: return launch_sk_fwd4_nlnw<nl, 1>(e, ka, st, done);               \
+    case 2: return launch_sk_fwd4_nlnw<nl, 2>(e, ka, st, done);               \
+    case 3: return launch_sk_fwd4_nlnw<nl, 3>(e, ka, st, done);               \
+    default: return launch_sk_fwd4_nlnw<nl, 4>(e, ka, st, done);              \
+  }
+  switch (NL) {
+    case 1: SK4_ROW(1)
+    case 2: SK4_ROW(2)
+    case 3: SK4_ROW(3)
+    default: SK4_ROW(4)
+  }
+#undef SK4_ROW
 }
 
 int launch_sk_step(sdrm_engine* e, const SkStepArgs& ka, int which, int grid, hipStream_t st) {
@@ -908,7 +942,7 @@ int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int on) {
 
 int sdrm_debug_set_skinny(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
-  e->tune.skinny = on ? 1 : 0;
+  e->tune.skinny = on < 0 ? 0 : (on > 2 ? 2 : on);
   return SDRM_OK;
 }
 
@@ -1069,7 +1103,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   }
   e->alpha_part_stride = std::max(max_gemm_blocks((int)MP, e->WP), (int)MP / 16);
   HIP_TRY(e, dalloc(&e->alpha_part, (size_t)(H + 1) * e->alpha_part_stride));
-  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, MP / SK_ROWS + 1))); HIP_TRY(e, dalloc(&e->sums, 8));
+  HIP_TRY(e, dalloc(&e->loss_part, (size_t)4 * std::max<size_t>(LOSS_BLOCKS, 4 * (MP / SK_ROWS + 1)))); HIP_TRY(e, dalloc(&e->sums, 8));
   if (e->LP <= 64 && e->WP <= 64 && T <= 128) {
     e->TPe = round_up(T, 16);
     HIP_TRY(e, dalloc(&e->WeP, (size_t)e->TPe * e->TPe)); HIP_TRY(e, dalloc(&e->W0eP, (size_t)e->WP * e->TPe));
@@ -1203,10 +1237,20 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     if (mode == SDRM_RNG_EXPLICIT) { ka.noise = rnd->noise; ka.t = rnd->t; ka.keep = rnd->keep; }
     ka.mode = mode; ka.seed_lo = (uint32_t)seed; ka.seed_hi = (uint32_t)(seed >> 32); ka.step = (uint32_t)step;
     ka.row0 = row0; ka.nd = nd;
-    rc = launch_sk_step(e, ka, 0, ka.G, st);
-    if (rc) return rc;
+    bool done4 = false;
+    if (e->tune.skinny == 1) {   // 4 users per work-group (csrc/skinny_fwd4.h); 2: the 16-user forward
+      ka.NP = 4 * ka.G;
+      rc = launch_sk_fwd4(e, ka, st, &done4);
+      if (rc) return rc;
+    }
+    if (!done4) {
+      ka.NP = ka.G;
+      rc = launch_sk_step(e, ka, 0, ka.G, st);
+      if (rc) return rc;
+    }
+    e->cur_sk_np = ka.NP;
     if (!e->fold_sums) {
-      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, ka.G, (double)B * (double)e->L,
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, ka.NP, (double)B * (double)e->L,
                          sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
@@ -1326,6 +1370,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     // slope gradient of a work-group's users in one launch; one slab set per work-group (the hidden layer's applications already
     // summed), at most S_MAX of them - a work-group then walks several groups of users
     SkStepArgs ka = sk_step_args(e, B);
+    ka.NP = e->cur_sk_np;
     ka.x0 = e->cur_x0; ka.sums = sa.sums; ka.count = sa.count; ka.loss = loss;
     const int S = std::min(ka.G, S_MAX);
     int rc = launch_sk_step(e, ka, 1, S, st);

@@ -48,7 +48,8 @@ struct SkStepArgs {
   int mode; uint32_t seed_lo, seed_hi, step; int64_t row0; float nd;
   // activations, grouped-by-16 stacked rows
   float* U; int* tdev; float* pre; size_t pre_stride; float* Y;   // U [MP][K0] (latent columns only), pre[k] [MP][WPs], Y [MP][LPs]
-  double* loss_part;                      // [G][4]
+  double* loss_part;                      // [NP][4]
+  int NP;                                 // loss partials the forward leaves: G (k_skinny_fwd) or 4 G (k_skinny_fwd4, one per 4 users)
   // backward
   const double* sums; double count; float* loss;
   float* slab0; float* slabH; float* slabO;        // [S][WPs][K0], [S][WPs][WPs], [S][LPs][WPs]: S = gridDim.x slab sets
@@ -405,15 +406,21 @@ __global__ __launch_bounds__(64 * 3 * (NL > NW ? NL : NW)) void k_skinny_bwd(con
     double* shs = shd;   // [4] totals
     if (wave == 0) {
       double tot[4] = {0, 0, 0, 0};
-      for (int vw = 0; vw < 4 && 64 * vw < a.G; ++vw) {
-        double v[4] = {0, 0, 0, 0};
-        for (int i = 64 * vw + lane; i < a.G; i += 256)
-          for (int j = 0; j < 4; ++j) v[j] += a.loss_part[4 * (size_t)i + j];
+      double v[4][4];   // [emulated wave][sum]: the first partial of every emulated wave's lane requested before any is used
+#pragma unroll
+      for (int vw = 0; vw < 4; ++vw)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[vw][j] = 64 * vw + lane < a.NP ? a.loss_part[4 * (size_t)(64 * vw + lane) + j] : 0.0;
+#pragma unroll
+      for (int vw = 0; vw < 4; ++vw) {
+        if (64 * vw >= a.NP) break;
+        for (int i = 64 * vw + lane + 256; i < a.NP; i += 256)
+          for (int j = 0; j < 4; ++j) v[vw][j] += a.loss_part[4 * (size_t)i + j];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += __shfl_down(v[j], off, 64);
-        for (int j = 0; j < 4; ++j) tot[j] += v[j];
+          for (int j = 0; j < 4; ++j) v[vw][j] += __shfl_down(v[vw][j], off, 64);
+        for (int j = 0; j < 4; ++j) tot[j] += v[vw][j];
       }
       if (lane == 0)
         for (int j = 0; j < 4; ++j) shs[j] = tot[j];

@@ -92,7 +92,7 @@ class Engine:
         if tile is not None:
             self._check(self.lib.sdrm_debug_set_tile(self._h, int(tile)), "sdrm_debug_set_tile")
         if skinny is not None:
-            self._check(self.lib.sdrm_debug_set_skinny(self._h, int(bool(skinny))), "sdrm_debug_set_skinny")
+            self._check(self.lib.sdrm_debug_set_skinny(self._h, int(skinny)), "sdrm_debug_set_skinny")
         if fused_reverse is not None:
             self._check(self.lib.sdrm_debug_set_fused_reverse(self._h, int(fused_reverse)), "sdrm_debug_set_fused_reverse")
         if chains is not None:

@@ -313,15 +313,17 @@ def test_train_step_vs_oracle(engine_cls, dims, train_path):
 
 @pytest.mark.parametrize("dims", [(40, 40, 93, 5, 850), (24, 56, 11, 3, 37), (64, 17, 8, 0, 5), (33, 48, 20, 1, 129)])
 def test_narrow_net_train_paths_agree(engine_cls, dims):
-    """Nets with widths <= 64 run their train forward and their whole backward (dgrad chain + every weight gradient) in the two
-    kernels of csrc/skinny_step.h (EXPLICIT and PHILOX staging); the general per-layer GEMM path must give the same step: P/S/Q,
-    loss, every gradient tensor, the parameters after Adam.  Same arithmetic, different summation order: 2e-5 normwise."""
+    """Nets with widths <= 64 run their train forward (csrc/skinny_fwd4.h: 4 users per work-group on 4x4x1 MFMAs; path 2:
+    csrc/skinny_step.h's 16-user forward, the fallback of shapes whose LDS image does not fit) and their whole backward (dgrad chain
+    + every weight gradient, csrc/skinny_step.h) in two kernels (EXPLICIT and PHILOX staging); the general per-layer GEMM path
+    must give the same step: P/S/Q, loss, every gradient tensor, the parameters after Adam.  Same arithmetic, different summation
+    order: 2e-5 normwise."""
     L, W, T, H, B = dims
     init = synth.flatten_params(synth.init_params(L, W, T, H, seed=16), H)
     x0 = synth.synth_latents(B, L, seed=17)
     eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=18)
     out = {}
-    for path in (1, 0):
+    for path in (1, 2, 0):
         for mode in ("explicit", "philox"):
             e = engine_cls(L, W, T, H, B).debug_set(skinny=path)
             e.set_params(init)
@@ -335,8 +337,8 @@ def test_narrow_net_train_paths_agree(engine_cls, dims):
             e.adam_step(1e-5)
             out[(path, mode)] = (loss, psq, grads, e.get_params().cpu().numpy())
             e.close()
-    for mode in ("explicit", "philox"):
-        (l1, p1, g1, w1), (l0, p0, g0, w0) = out[(1, mode)], out[(0, mode)]
+    for mode, path in [(m, q) for m in ("explicit", "philox") for q in (1, 2)]:
+        (l1, p1, g1, w1), (l0, p0, g0, w0) = out[(path, mode)], out[(0, mode)]
         assert abs(l1 - l0) <= 2e-5 * abs(l0), (mode, l1, l0)
         assert close(p1, p0, 2e-5), (mode, rel_max(p1, p0))
         for (n, a), (_, b) in zip(per_tensor(g1, dims[:4]), per_tensor(g0, dims[:4])):
