@@ -73,6 +73,71 @@ __global__ __launch_bounds__(256) void k_rowsync(float* buf, unsigned int* cnt, 
   if (errors) atomicAdd(bad, errors);
 }
 
+// Round 4: the same hand-over THROUGH ONE XCD's L2.  Row tile R lives on XCD R % 8 - all six of its work-groups (work-group b runs on
+// XCD b & 7; slot b / 8 of that XCD = (row tile index on the XCD, column tile)) - so nothing has to be coherent beyond that L2:
+// the counter is incremented by work-group-scope atomics (executed in the L2), polled by an sc1 load; the tiles are written by
+// plain stores (acknowledged by the L2 before the signal) and read by sc1 loads (not from the CU's L1, where a line of an
+// earlier phase may sit), eight 16-byte loads in flight per thread.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned poll_sc1(const unsigned* p) {
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void load_sc1x8(const float* p, f32x4v (&v)[8]) {   // p, p + 4 KiB, ..
+  const char* q = reinterpret_cast<const char*>(p);
+  const char *q1 = q + 4096, *q2 = q + 8192, *q3 = q + 12288, *q4 = q + 16384, *q5 = q + 20480, *q6 = q + 24576, *q7 = q + 28672;
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(q), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7)
+      : "memory");
+}
+constexpr int SLOTS = ((ROWS + 7) / 8) * COLS;   // work-groups per XCD (the XCDs with a row tile fewer leave six idle)
+
+__global__ __launch_bounds__(256) void k_rowsync_l2(float* buf, unsigned int* cnt, unsigned int* abort_, int phases, int data, int* bad) {
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int R = x + 8 * (slot / COLS), c = slot % COLS;
+  if (R >= ROWS) return;
+  const int tid = threadIdx.x;
+  int errors = 0;
+  __shared__ int go;
+  for (int p = 0; p < phases; ++p) {
+    float* mine = buf + ((size_t)(p & 1) * NB + (size_t)R * COLS + c) * TILE;
+    if (data)
+      for (int i = 4 * tid; i < TILE; i += 1024)
+        *reinterpret_cast<float4*>(mine + i) = make_float4(tile_value(p, R, c, i), tile_value(p, R, c, i + 1), tile_value(p, R, c, i + 2), tile_value(p, R, c, i + 3));
+    __syncthreads();   // every thread's stores are acknowledged (s_waitcnt vmcnt(0) before the barrier)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt + 32 * R, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned int target = (unsigned int)COLS * (unsigned int)(p + 1);
+      int ok = 0;
+      for (unsigned int spins = 0; spins < (1u << 18); ++spins) {
+        if (poll_sc1(cnt + 32 * R) >= target) { ok = 1; break; }
+        if ((spins & 255u) == 255u && __hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
+      if (!ok) __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      go = ok;
+    }
+    __syncthreads();
+    if (!go) break;
+    if (data) {
+      const float* row = buf + ((size_t)(p & 1) * NB + (size_t)R * COLS) * TILE;
+      for (int i = 4 * tid; i < COLS * TILE; i += 8 * 1024) {   // COLS * TILE = 24576 floats = 3 x 8192
+        f32x4v v[8];
+        load_sc1x8(row + i, v);
+        for (int u = 0; u < 8; ++u) {
+          const int ii = i + 1024 * u, cc = ii / TILE, jj = ii % TILE;
+          for (int e = 0; e < 4; ++e) errors += v[u][e] != tile_value(p, R, cc, jj + e);
+        }
+      }
+    }
+  }
+  if (errors) atomicAdd(bad, errors);
+}
+
 // the same data movement as one launch per phase: write the tile of phase p, check the row's tiles of phase p - 1
 __global__ __launch_bounds__(256) void k_phase(float* buf, int p, int* bad) {
   const int logical = xcd_remap(blockIdx.x, NB);
@@ -117,6 +182,27 @@ int main() {
       if (rc != hipSuccess || habort) { printf("mode %d: rc %s abort %u\n", mode, hipGetErrorString(rc), habort); break; }
     }
     printf("persistent, row-tile sync, %-58s: %6.2f us per phase   wrong values %d   timed out %u\n", names[mode], best * 1e3 / phases, hbad, habort);
+  }
+  {
+    unsigned int* cnt2; hipMalloc(&cnt2, ROWS * 32 * 4);
+    const char* n2[2] = {"handshake only, through the row tile's XCD's L2 (round 4)", "plain stores / sc1 loads through that L2, work-group-scope counter"};
+    for (int data = 0; data < 2; ++data) {
+      float best = 1e30f;
+      int hbad = 0; unsigned int habort = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipMemset(cnt2, 0, ROWS * 32 * 4); hipMemset(abort_, 0, 4); hipMemset(bad, 0, 4);
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_rowsync_l2, dim3(8 * SLOTS), dim3(256), 0, 0, buf, cnt2, abort_, phases, data, bad);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+        hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost); hipMemcpy(&habort, abort_, 4, hipMemcpyDeviceToHost);
+        if (habort) break;
+      }
+      printf("persistent, row-tile sync, %-66s: %6.2f us per phase   wrong values %d   timed out %u\n", n2[data], best * 1e3 / phases, hbad, habort);
+    }
   }
   {
     float best = 1e30f;
