@@ -223,3 +223,31 @@ def test_strips_kernel_loop_is_clean():
         assert not [x for x in body if x.startswith("scratch_")]
         valu = [x for x in body if x.startswith("v_") and not x.startswith(("v_mfma", "v_accvgpr_read"))]
         assert len(valu) * 8 <= nm, (len(valu), nm, valu[:6])
+
+
+def test_narrow_forward_layer_reads_precede_its_mfmas():
+    """k_skinny_fwd4 (csrc/skinny_fwd4.h): a hidden layer of a wave is twelve ds_read_b128 and 48 v_mfma_f32_4x4x1_16b_f32.  Left
+    to itself the scheduler pairs every read with its four MFMAs - twelve exposed LDS round trips per layer (1277 cycles measured
+    against 711) - so the source pins the reads in front (sched_group_barrier): here the hidden-layer loop must hold no scratch
+    access, and at most two LDS reads may follow the first MFMA of the loop body."""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "k.hip")
+        with open(src, "w") as f:
+            f.write(f'#include "{CSRC}/skinny_fwd4.h"\ntemplate __global__ void sdrm::k_skinny_fwd4<3, 3>(const sdrm::SkStepArgs);\n')
+        out = os.path.join(d, "k.s")
+        res = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        asm = open(out).read()
+    ks = _kernels(asm)
+    (name,) = [n for n in ks if "k_skinny_fwd4" in n]
+    ins = ks[name]
+    assert not [x for x in ins if x.startswith("scratch_")]
+    assert sum(1 for x in ins if x.startswith("v_mfma_f32_4x4x1")) == 3 * 48
+    loops = _loops(ins)
+    hidden = [(a, b) for a, b in loops if sum(1 for x in ins[a:b] if x.startswith("v_mfma_f32_4x4x1")) == 48]
+    assert hidden, "the hidden-layer loop was not found"
+    for a, b in hidden:
+        body = ins[a:b]
+        first = next(i for i, x in enumerate(body) if x.startswith("v_mfma_f32_4x4x1"))
+        assert sum(1 for x in body[first:] if x.startswith("ds_read_b128")) <= 2, [x for x in body[first:] if x.startswith("ds_read")]
