@@ -212,13 +212,14 @@ __global__ __launch_bounds__(256) void k_prep_train(const PrepTrainArgs a) {
   // one thread per group of four columns of one staged row triple (16-byte stores; the row's t is drawn once
   // per thread instead of once per column pair)
   const int QP = a.K0 >> 2;
-  const int64_t i0 = (int64_t)((int)blockIdx.x - a.emb_blocks) * 256;
-  const int64_t i = i0 + threadIdx.x;
-  const int r = (int)(i / QP);
-  const int c = 4 * (int)(i - (int64_t)r * QP);
+  // (staged rows x column quads: below 2^32 for every shape sdrm_create accepts - 32-bit divisions: a 64-bit one is ~100 instructions)
+  const uint32_t i0 = (uint32_t)((int)blockIdx.x - a.emb_blocks) * 256u;
+  const uint32_t i = i0 + threadIdx.x;
+  const int r = (int)(i / (uint32_t)QP);
+  const int c = 4 * (int)(i - (uint32_t)r * (uint32_t)QP);
   // the timesteps of the (at most 18: K0 >= 64) rows this block touches, drawn once per row
   __shared__ int tts[20];
-  const int r_first = (int)(i0 / QP), r_last = (int)((i0 + 255) / QP);
+  const int r_first = (int)(i0 / (uint32_t)QP), r_last = (int)((i0 + 255u) / (uint32_t)QP);
   if ((int)threadIdx.x <= r_last - r_first) {
     const int rr = r_first + (int)threadIdx.x;
     int t0 = 0;
@@ -358,16 +359,40 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return s;
 }
 
+// four sums at once, each by block_sum's own tree (shuffles down the wave, then the waves' results added in wave order): the same
+// bits, one barrier pair instead of four.  sh: [4 * waves].  The totals are valid in thread 0 only.
+__device__ __forceinline__ void block_sum4_seq(double (&v)[4], double* sh) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[j] += __shfl_down(v[j], off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[4 * wave + j] = v[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double t = 0.0;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[4 * w + j];
+      v[j] = t;
+    }
+  }
+}
+
 // 1024 threads per work-group: an iteration is one dependent round trip (four independent 16-byte loads, then the
 // sums), so the launch takes as long as its iterations per thread - 3 instead of 11 at B = 8192, L = 340.
 __global__ __launch_bounds__(1024) void k_loss_partials(const LossArgs a) {
-  __shared__ double sh[16];
+  __shared__ double sh[4 * 16];
   double sD = 0, sC = 0, sR = 0, sR2 = 0;
   const int QP = a.LP >> 2;
-  const size_t total = (size_t)a.B * QP;
+  const uint32_t total = (uint32_t)a.B * (uint32_t)QP;   // (rows x column quads: below 2^32 for every shape sdrm_create accepts)
   const size_t BLP = (size_t)a.B * a.LP;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / QP), c = 4 * (int)(i - (size_t)r * QP);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = (int)(i / (uint32_t)QP), c = 4 * (int)(i - (uint32_t)r * (uint32_t)QP);   // (32-bit: a 64-bit division is ~100 instructions)
     if (c >= a.L) continue;
     const size_t yi = (size_t)r * a.LP + c;
     const float4 P = *reinterpret_cast<const float4*>(a.Y + yi);
@@ -388,10 +413,11 @@ __global__ __launch_bounds__(1024) void k_loss_partials(const LossArgs a) {
     }
     sD += fD; sC += fC; sR += fR; sR2 += fR2;
   }
-  const double tD = block_sum(sD, sh), tC = block_sum(sC, sh), tR = block_sum(sR, sh), tR2 = block_sum(sR2, sh);
+  double t4[4] = {sD, sC, sR, sR2};
+  block_sum4_seq(t4, sh);
   if (threadIdx.x == 0) {
     double* o = a.part + 4 * (size_t)blockIdx.x;
-    o[0] = tD; o[1] = tC; o[2] = tR; o[3] = tR2;
+    o[0] = t4[0]; o[1] = t4[1]; o[2] = t4[2]; o[3] = t4[3];
   }
 }
 
@@ -425,14 +451,13 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   if (a.sums) {
     s0 = a.sums[0]; s1 = a.sums[1]; s2 = a.sums[2]; s3 = a.sums[3]; N = a.sums[4];
   } else {
-    __shared__ double shs[4], tot[4];
+    __shared__ double shs[4 * 4], tot[4];
     double v[4] = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < a.nblk; i += blockDim.x)
       for (int j = 0; j < 4; ++j) v[j] += a.part[4 * (size_t)i + j];
-    for (int j = 0; j < 4; ++j) {
-      const double t = block_sum(v[j], shs);
-      if (threadIdx.x == 0) tot[j] = t;
-    }
+    block_sum4_seq(v, shs);   // (k_loss_sums' tree per sum, one barrier pair for the four)
+    if (threadIdx.x == 0)
+      for (int j = 0; j < 4; ++j) tot[j] = v[j];
     __syncthreads();
     s0 = tot[0]; s1 = tot[1]; s2 = tot[2]; s3 = tot[3]; N = a.count;
   }
@@ -453,8 +478,8 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   // grid-stride (the host caps the grid at 2048 work-groups): the fold above - eight block barriers - is paid once for the
   // two or three column quads a thread then handles (B = 8192: train step 580.5 -> 578.3 us on one box)
   for (size_t flat = (size_t)blockIdx.x * 256 + threadIdx.x; flat < total; flat += (size_t)gridDim.x * 256) {
-    const int r = (int)(flat / QP);
-    const int c = 4 * (int)(flat - (size_t)r * QP);
+    const int r = (int)((uint32_t)flat / (uint32_t)QP);   // (rows x column quads: below 2^32; a 64-bit division is ~100 instructions)
+    const int c = 4 * (int)((uint32_t)flat - (uint32_t)r * (uint32_t)QP);
     if (r >= nslots) {
       *reinterpret_cast<float4*>(a.dY + (size_t)(3 * nslots + (r - nslots)) * a.LP + c) = zero;
       continue;
