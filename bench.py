@@ -405,6 +405,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
 
+    if stub and os.environ.get("SDRM_BENCH_TEST_FAIL_RANK_LATE") == str(rank):
+        # (test hook: a rank that dies AFTER the rendezvous - its peers are then inside collectives; the launcher must end them)
+        raise SystemExit(f"bench.py: rank {rank} asked to fail after the rendezvous (test hook of tests/test_bench_launch.py)")
     if stub:
         sys.path.insert(0, os.path.join(REPO, "tests"))
         from bench_stub import StubEngine as Engine

@@ -47,7 +47,8 @@ enum sdrm_status {
   SDRM_ERR_HIP = -3,    /* a HIP runtime call failed */
   SDRM_ERR_STATE = -4,  /* call order violated (e.g. backward before forward) */
   SDRM_ERR_NOMEM = -5,
-  SDRM_ERR_RCCL = -6    /* librccl could not be loaded, or an RCCL call failed */
+  SDRM_ERR_RCCL = -6,   /* librccl could not be loaded, or an RCCL call failed */
+  SDRM_ERR_DEVICE = -7  /* the device is not the chip this library is built for (gfx950, 256 compute units) */
 };
 
 /* Where the randomness of a call comes from (SURVEY.md §8b "two RNG modes"). */
@@ -69,8 +70,10 @@ typedef struct sdrm_train_randoms {
 /* Builds an engine for an eps-predictor SDRM(N_ITEMS=L, EMB_DIM=T, LATENT_DIM=W, n_hidden_layers=H)
  * (train_SDRM.py:86-95, :305) able to process up to max_rows rows per call, with Adam state
  * (train_SDRM.py:309) and the DDPM schedule for beta1=1e-4, beta2=0.02 (train_SDRM.py:275-276,
- * 300-303).  Parameters start at zero: call sdrm_set_params.  Envelope: 1<=L,W<=4096, 2<=T<=1024,
- * 0<=H<=16 (the reference's search space, hyperparameter_search.py:103-113, is L=W<=1000, T<=198, H<=5). */
+ * 300-303).  Parameters start at zero: call sdrm_set_params.  Envelope: 1<=L,W<=4096, 2<=T<=1020,
+ * 0<=H<=16 (the reference's search space, hyperparameter_search.py:103-113, is L=W<=1000, T<=198, H<=5).
+ * The device must be a gfx950 with 256 compute units (MI355X in SPX mode): the one-round launches (one work-group per CU) and
+ * the work-group -> XCD mapping are sized for it, anything else is refused with SDRM_ERR_DEVICE rather than run mis-balanced. */
 int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_engine** out);
 int sdrm_destroy(sdrm_engine* e);
 const char* sdrm_last_error(const sdrm_engine* e);
@@ -238,10 +241,16 @@ const char* sdrm_source_hash(void);
 /* Sparse batch feed (reference: dataloaders.py:46-79 builds a COO tensor per batch on the host, train_SDRM.py:323
  * densifies it before vae.encode).  The CSR matrix of the whole feed [n_rows, n_items] stays on the device (int64
  * indptr, int32 column indices, float32 data or null for all-ones); out [b, n_items] float32 receives the dense rows
- * rows[0..b) (device int64 array; the caller's epoch permutation) or, when rows is null, rows row0 .. row0+b-1.
- * Row ids and column indices are not range-checked. */
-int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data,
+ * rows[0..b) (device int64 array; the caller's epoch permutation) or, when rows is null, rows row0 .. row0+b-1
+ * (checked on the host against n_rows).  The caller's CSR is not trusted with the address of a store: on the device every
+ * row id is checked against [0, n_rows), every indptr pair for order, every column index against [0, n_items); an offending
+ * row / entry is left zero and recorded in the handle's feed status word, which sdrm_feed_status reports. */
+int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data, int64_t n_rows,
                            const int64_t* rows, int64_t row0, int b, int n_items, float* out, void* stream);
+/* SDRM_OK, or SDRM_ERR_ARG (message: what was out of range) if any sdrm_csr_rows_to_dense launch since the last call met an
+ * out-of-range row id, indptr pair or column index; clears the record.  Synchronises `stream` (call it once per epoch, not per
+ * batch). */
+int sdrm_feed_status(sdrm_engine* e, void* stream);
 
 /* Equal-sparsity binarisation of sampled data on the device (reference: main.py:177-180,
  *   threshold = np.quantile(M.flatten(), SPARSITY); M_equal_sparsity = (M >= threshold)):

@@ -16,6 +16,10 @@
 extern "C" {
 #endif
 
+/* What sdrm_create checks of the device: SDRM_OK for a gfx950 (architecture string as hipDeviceProp_t::gcnArchName gives it,
+ * e.g. "gfx950:sramecc+:xnack-") with 256 compute units, SDRM_ERR_DEVICE otherwise.  Pure function: callable without a GPU. */
+int sdrm_debug_device_check(const char* gcn_arch, int compute_units);
+
 /* Tile shapes of the MFMA GEMM template, as numbered by sdrm_debug_set_tile / the `cfg` arguments below:
  *   0 = 64x64x16 (default), 1 = 64x64x32, 2 = 64x128x16, 3 = 128x128x16 on v_mfma_f32_32x32x2_f32,
  *   4 = 32x32x32 on v_mfma_f32_16x16x4_f32. */

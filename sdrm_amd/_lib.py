@@ -77,7 +77,8 @@ SIGNATURES = {
     "sdrm_profile_get": (c_int, [c_void_p, c_int, C.POINTER(C.c_double), C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "sdrm_launch_count": (c_int64, [c_void_p]),
     "sdrm_build_info": (C.c_char_p, []),
-    "sdrm_csr_rows_to_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sdrm_csr_rows_to_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "sdrm_feed_status": (c_int, [c_void_p, c_void_p]),
     "sdrm_vae_decode": (c_int, [c_void_p, C.POINTER(VaeDecoder), c_void_p, c_int, c_void_p, c_void_p]),
     "sdrm_equal_sparsity": (c_int, [c_void_p, c_void_p, c_int64, C.c_double, c_void_p, c_void_p, c_void_p]),
     "sdrm_rank_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -85,6 +86,7 @@ SIGNATURES = {
     "sdrm_source_hash": (C.c_char_p, []),
     # include/sdrm_hip_debug.h (test / tuning hooks; every setter acts on one handle)
     "sdrm_debug_philox_draws": (c_int, [c_void_p, c_uint64, C.c_uint32, C.c_uint32, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "sdrm_debug_device_check": (c_int, [C.c_char_p, c_int]),
     "sdrm_debug_set_tile": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_nt32_rows": (c_int, [c_void_p, c_int, c_int]),
     "sdrm_debug_set_chains": (c_int, [c_void_p, c_int]),
@@ -102,7 +104,7 @@ SIGNATURES = {
 
 RNG_EXPLICIT, RNG_PHILOX = 0, 1
 STATUS = {0: "SDRM_OK", -1: "SDRM_ERR_ARG", -2: "SDRM_ERR_SHAPE", -3: "SDRM_ERR_HIP", -4: "SDRM_ERR_STATE",
-          -5: "SDRM_ERR_NOMEM", -6: "SDRM_ERR_RCCL"}
+          -5: "SDRM_ERR_NOMEM", -6: "SDRM_ERR_RCCL", -7: "SDRM_ERR_DEVICE"}
 
 
 def lib_path() -> str:

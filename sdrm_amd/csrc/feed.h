@@ -12,9 +12,13 @@ namespace sdrm {
 struct FeedArgs {
   const int64_t* indptr; const int32_t* indices; const float* data;   // CSR of the whole feed [n_rows, n_items]
   const int64_t* rows;     // [b] row ids of this batch (null: rows row0 .. row0+b-1)
-  int64_t row0; int b, n_items;
+  int64_t row0, n_rows; int b, n_items;
   float* out;              // [b, n_items]
+  unsigned* flag;          // the handle's feed status word: bit 0 a row id outside [0, n_rows), bit 1 a column index outside
+                           // [0, n_items), bit 2 a row whose indptr pair is not ordered (read by sdrm_feed_status)
 };
+
+enum { FEED_BAD_ROW = 1u, FEED_BAD_COL = 2u, FEED_BAD_PTR = 4u };
 
 __global__ __launch_bounds__(256) void k_csr_rows_to_dense(const FeedArgs a) {
   const int r = blockIdx.x;
@@ -29,8 +33,25 @@ __global__ __launch_bounds__(256) void k_csr_rows_to_dense(const FeedArgs a) {
   for (int i = threadIdx.x; i < nv; i += 256) d4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = h + 4 * nv + threadIdx.x; i < a.n_items; i += 256) dst[i] = 0.f;
   __syncthreads();   // the scatter below must land after this block's own zero stores (same work-group, same row)
+  // A caller's CSR is not trusted with the address of a store: a row id or column index outside the matrix leaves the output
+  // row / that entry zero and raises the handle's status word instead of writing out of bounds (uniform branches; the compare
+  // per entry is free beside its scattered 4-byte store).
+  if (src < 0 || src >= a.n_rows) {
+    if (threadIdx.x == 0) atomicOr(a.flag, (unsigned)FEED_BAD_ROW);
+    return;
+  }
   const int64_t p0 = a.indptr[src], p1 = a.indptr[src + 1];
-  for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) dst[a.indices[p]] = a.data ? a.data[p] : 1.f;
+  if (p0 < 0 || p1 < p0) {
+    if (threadIdx.x == 0) atomicOr(a.flag, (unsigned)FEED_BAD_PTR);
+    return;
+  }
+  bool bad = false;
+  for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int32_t c = a.indices[p];
+    if (c < 0 || c >= a.n_items) bad = true;
+    else dst[c] = a.data ? a.data[p] : 1.f;
+  }
+  if (bad) atomicOr(a.flag, (unsigned)FEED_BAD_COL);
 }
 
 }  // namespace sdrm

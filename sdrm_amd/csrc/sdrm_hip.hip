@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -109,6 +111,7 @@ struct sdrm_engine {
   float *rev_dev = nullptr;          // [3][T+1] reverse-step coefficients c1, sqrt(alpha), sqrt(beta)
   SelectState* sel = nullptr;        // radix-select workspace of sdrm_equal_sparsity
   float* one_dev = nullptr;          // 1.0f (identity PReLU slope for layer 0 inside the batched weight-gradient launch)
+  unsigned* feed_flag = nullptr;     // status word of the sparse batch feed (csrc/feed.h: out-of-range row ids / column indices)
   std::vector<int> smp_nact, smp_perm;
   std::vector<int64_t> smp_tj_sorted, smp_tj_orig;
   std::vector<float> h_beta, h_alpha, h_alphabar;
@@ -199,6 +202,20 @@ int fail(sdrm_engine* e, int code, const std::string& msg) {
 }
 
 constexpr size_t SLACK = 4096;  // elements of zeroed tail on every buffer: unguarded tile loads may run past a matrix
+
+// Dynamic LDS above 48 KB needs the kernel's limit raised.  Raised ONCE per kernel and process, to the whole 160 KB of a CU: a
+// per-launch call is host time on every step of the narrow nets, and a per-engine value would let a second engine with a smaller
+// image lower the limit under a first one with a larger image.
+constexpr int LDS_MAX_BYTES = 160 * 1024;
+hipError_t allow_full_lds(const void* kernel) {
+  static std::mutex mu;
+  static std::set<const void*> done;
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(kernel)) return hipSuccess;
+  const hipError_t st = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES);
+  if (st == hipSuccess) done.insert(kernel);
+  return st;
+}
 
 template <typename Tp>
 hipError_t dalloc(Tp** p, size_t n) {
@@ -575,8 +592,10 @@ int emb_tables(sdrm_engine* e, hipStream_t st, const float* warm = nullptr, size
   e->tables_fresh = true;
   return SDRM_OK;
 }
-// ... made only when the parameters changed since they were last made (sdrm_set_params, sdrm_adam_step, a train step whose tail
-// did not make them itself: csrc/tail.h, k_tail_emb_tab)
+// ... made only when the parameters changed since they were last made (sdrm_set_params, sdrm_adam_step, every train step: the tail
+// updates the parameters and clears `tables_fresh`; the tables are then made by the next consumer - k_emb_tables in front of the
+// row-owned forward, the leading blocks of k_prep_train, the narrow nets' forward itself when T <= 128, or this launch: narrow
+// nets with T > 128 and the sampler pay it as a launch of its own)
 int ensure_tables(sdrm_engine* e, hipStream_t st) { return e->tables_fresh ? SDRM_OK : emb_tables(e, st); }
 
 bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && e->WP <= 64; }
@@ -742,10 +761,7 @@ template <int NL, int NW>
 int launch_sk_step_nlnw(sdrm_engine* e, const SkStepArgs& ka, int which, int grid, hipStream_t st) {
   typedef SkCfg<NL, NW> C;
   const size_t lds = (which == 0 ? sk_fwd_lds_floats<NL, NW>(ka.intab ? ka.TPe : 0) : sk_bwd_lds_floats<NL, NW>(ka.TPs)) * sizeof(float);
-  if (lds > 48 * 1024) {
-    if (which == 0) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_bwd<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
+  if (lds > 48 * 1024) HIP_TRY(e, allow_full_lds(which == 0 ? (const void*)k_skinny_fwd<NL, NW> : (const void*)k_skinny_bwd<NL, NW>));
   if (which == 0) SDRM_LAUNCH(e, (k_skinny_fwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
   else SDRM_LAUNCH(e, (k_skinny_bwd<NL, NW>), dim3((unsigned)grid), dim3(C::NTHR), lds, st, ka);
   HIP_TRY(e, hipGetLastError());
@@ -759,7 +775,7 @@ int launch_sk_fwd4_nlnw(sdrm_engine* e, const SkStepArgs& ka, hipStream_t st, bo
   const size_t lds = sk4_fwd_lds_floats<NL, NW>(ka.intab ? ka.TPe : 0) * sizeof(float);
   *done = false;
   if (lds > 160 * 1024) return SDRM_OK;
-  if (lds > 48 * 1024) HIP_TRY(e, hipFuncSetAttribute((const void*)k_skinny_fwd4<NL, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (lds > 48 * 1024) HIP_TRY(e, allow_full_lds((const void*)k_skinny_fwd4<NL, NW>));
   SDRM_LAUNCH(e, (k_skinny_fwd4<NL, NW>), dim3((unsigned)std::min(ka.NP, 8192)), dim3(SK4_THREADS), lds, st, ka);
   HIP_TRY(e, hipGetLastError());
   *done = true;
@@ -1008,10 +1024,22 @@ const char* sdrm_build_info(void) {
   return "gfx950 fp32 v_mfma_f32_32x32x2_f32; block tile 64x64x16 (32x32x32 on v_mfma_f32_16x16x4_f32 for NT launches of at "
          "most 4096 rows, 8192 stacked rows in the train step), 4 waves, two LDS stages + register-double-buffered fragments, "
          "pipeline pieces in the MFMA shadows, k-minor LDS + ds_read_b128 for NT; split-K slabs for wgrad; persistent "
-         "LDS-resident kernels for widths <= 64; sources " SDRM_SOURCE_HASH;
+         "LDS-resident kernels for widths <= 64; one-round grids sized for 256 compute units in 8 XCDs (sdrm_create refuses any "
+         "other device); sources " SDRM_SOURCE_HASH;
 }
 
 const char* sdrm_last_error(const sdrm_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+// The chip this library is written for: gfx950 with all 256 compute units in one device (MI355X, SPX mode).  The one-round grids
+// (k_row_fwd, k_dgrad_chain, k_wgrad_strips: one work-group per CU), the split-K plans (1280 resident work-groups) and the
+// work-group -> XCD mapping (block b on XCD b & 7, xcd_remap) are sized for exactly that; on another CU count they would run,
+// silently mis-balanced.  sdrm_create refuses instead (SDRM_ALLOW_ANY_DEVICE=1 lifts the CU-count check for experiments).
+constexpr int SDRM_TARGET_CUS = 256;
+int sdrm_debug_device_check(const char* gcn_arch, int compute_units) {
+  if (!gcn_arch) return SDRM_ERR_ARG;
+  if (std::strncmp(gcn_arch, "gfx950", 6) != 0 || (gcn_arch[6] != '\0' && gcn_arch[6] != ':')) return SDRM_ERR_DEVICE;
+  return compute_units == SDRM_TARGET_CUS ? SDRM_OK : SDRM_ERR_DEVICE;
+}
 int64_t sdrm_param_count(const sdrm_engine* e) { return e ? e->P : -1; }
 
 int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_engine** out) {
@@ -1020,6 +1048,9 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (L < 1 || L > 4096 || W < 1 || W > 4096 || T < 2 || T > 1024 || H < 0 || H > 16 || max_rows < 1 ||
       max_rows > (1 << 22))
     return SDRM_ERR_SHAPE;
+  // k_tail_emb (csrc/tail.h) keeps TE_JT rows of emb_layer.weight beside a [TE_RB][TP] block of M in LDS: the image grows with T and
+  // passes the CU's 160 KB at T = 1021 (the reference's search space ends at T = 198, hyperparameter_search.py:108)
+  if (tail_emb_lds_floats(T, round_up(T + 1, 32)) * sizeof(float) > 160 * 1024) return SDRM_ERR_SHAPE;
   sdrm_engine* e = new sdrm_engine();
   // the only place the environment is read: the settings then belong to this handle
   if (const char* env = std::getenv("SDRM_TILE")) e->tune.force_cfg = std::atoi(env);
@@ -1055,6 +1086,16 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   e->P = o;
   *out = e;  // handed out even on failure below so the caller can read the message and destroy
   HIP_TRY(e, hipSetDevice(device_id));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(e, hipGetDeviceProperties(&prop, device_id));
+    const char* any = std::getenv("SDRM_ALLOW_ANY_DEVICE");
+    const bool lifted = any && std::atoi(any) != 0;
+    if (sdrm_debug_device_check(prop.gcnArchName, lifted ? SDRM_TARGET_CUS : prop.multiProcessorCount) != SDRM_OK)
+      return fail(e, SDRM_ERR_DEVICE, std::string("sdrm_create: device ") + std::to_string(device_id) + " is " + prop.gcnArchName + " with " +
+                                          std::to_string(prop.multiProcessorCount) + " compute units; this library is built for gfx950 with " +
+                                          std::to_string(SDRM_TARGET_CUS) + " (MI355X, SPX mode): its one-round grids and XCD mapping assume them");
+  }
   const size_t MP = e->MPmax;
   const int n = T + 1;
   HIP_TRY(e, dalloc(&e->p, e->P)); HIP_TRY(e, dalloc(&e->m, e->P));
@@ -1083,6 +1124,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   }
   HIP_TRY(e, dalloc(&e->sel, 1));
   HIP_TRY(e, dalloc(&e->one_dev, 4));
+  HIP_TRY(e, dalloc(&e->feed_flag, 4));
   {
     const float one = 1.0f;
     HIP_TRY(e, hipMemcpy(e->one_dev, &one, 4, hipMemcpyHostToDevice));
@@ -1109,8 +1151,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     HIP_TRY(e, dalloc(&e->WeP, (size_t)e->TPe * e->TPe)); HIP_TRY(e, dalloc(&e->W0eP, (size_t)e->WP * e->TPe));
   }
   HIP_TRY(e, dalloc(&e->Mred, (size_t)W * e->TP)); HIP_TRY(e, dalloc(&e->snap, (size_t)T * T + T + (size_t)W * T));
-  if (tail_emb_lds_floats(T, e->TP) * sizeof(float) > 48 * 1024)
-    HIP_TRY(e, hipFuncSetAttribute((const void*)k_tail_emb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tail_emb_lds_floats(T, e->TP) * sizeof(float))));
+  HIP_TRY(e, allow_full_lds((const void*)k_tail_emb));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int c = 0; c < 3; ++c) {
@@ -1130,7 +1171,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->tembP, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->feed_flag, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -1284,8 +1325,8 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   pa.mode = mode; pa.seed_lo = (uint32_t)seed; pa.seed_hi = (uint32_t)(seed >> 32); pa.step = (uint32_t)step;
   pa.row0 = row0; pa.nd = nd;
   {
-    // the step's tables ride on the staging launch: E (embedding backward), C0^T in the trailing columns of W0c (what the
-    // plain-forward path multiplies the one-hot columns with) and B0tab = b0 + C0[t], which layer 0 below adds per row
+    // the step's tables ride on the staging launch: C0^T in the trailing columns of W0c (what the plain sdrm_forward multiplies its
+    // one-hot(t) columns with) and B0tab = b0 + C0[t], which layer 0 below adds per row
     pa.emb = emb_args(e);
     e->tables_fresh = true;
     pa.emb_row0 = B + (MP - 3 * B);
@@ -1297,8 +1338,8 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   }
   {
     // Layer 0 contracts over the latent columns only (K = LP instead of LP + TP: a fifth less work at ML-1M): every row's
-    // time-embedding term is a row of B0tab, added in the epilogue.  The one-hot columns of U stay: the layer-0 weight
-    // gradient multiplies them to deliver dC0.
+    // time-embedding term is a row of B0tab, added in the epilogue.  The trailing columns of U carry temb[t_row] (round 4; before: a
+    // one-hot(t)): the layer-0 weight gradient multiplies them to deliver M = dpre0^T * temb (csrc/tail.h).
     GemmArgs a{};
     a.C = pre_buf(e, 0); a.ldc = e->WP; a.bias = e->B0tab; a.ldtab = e->WP; a.trow = e->tdev; a.trow_B = B;
     HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_ROWTAB>(a, e->U, e->K0, e->W0c, e->K0, MP, e->WP, e->LP, st,
@@ -1336,7 +1377,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
 // measured: the two cross-stream event waits cost more than the ~45 us they hide, 642 vs 627 us per step.)
 namespace {
 
-// loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose one-hot columns deliver dC0)
+// loss seeds, the dgrad chain down to layer 0, and the layer-0 weight gradient (whose time-embedding columns deliver M, csrc/tail.h)
 int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t st, bool with_wgrad0) {
   const int B = e->cur_B, MP = e->cur_MP, H = e->H;
   e->bwd_strips = false;
@@ -2116,15 +2157,33 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
 
 // ---------------------------------------------------------------------------------------------
 // Sparse batch feed (dataloaders.py:46-79, train_SDRM.py:323), csrc/feed.h.
-int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data,
+int sdrm_csr_rows_to_dense(sdrm_engine* e, const int64_t* indptr, const int32_t* indices, const float* data, int64_t n_rows,
                            const int64_t* rows, int64_t row0, int b, int n_items, float* out, void* stream) {
   if (!e || !indptr || !indices || !out) return fail(e, SDRM_ERR_ARG, "sdrm_csr_rows_to_dense: null pointer");
-  if (b < 1 || n_items < 1 || row0 < 0) return fail(e, SDRM_ERR_SHAPE, "sdrm_csr_rows_to_dense: b < 1, n_items < 1 or row0 < 0");
+  if (b < 1 || n_items < 1 || row0 < 0 || n_rows < 1)
+    return fail(e, SDRM_ERR_SHAPE, "sdrm_csr_rows_to_dense: b < 1, n_items < 1, n_rows < 1 or row0 < 0");
+  if (!rows && row0 + b > n_rows) return fail(e, SDRM_ERR_SHAPE, "sdrm_csr_rows_to_dense: rows row0 .. row0 + b - 1 end behind the matrix");
   FeedArgs a{};
-  a.indptr = indptr; a.indices = indices; a.data = data; a.rows = rows; a.row0 = row0; a.b = b; a.n_items = n_items; a.out = out;
+  a.indptr = indptr; a.indices = indices; a.data = data; a.rows = rows; a.row0 = row0; a.n_rows = n_rows; a.b = b; a.n_items = n_items;
+  a.out = out; a.flag = e->feed_flag;
   SDRM_LAUNCH(e, k_csr_rows_to_dense, dim3(b), dim3(256), 0, (hipStream_t)stream, a);
   HIP_TRY(e, hipGetLastError());
   return SDRM_OK;
+}
+
+// what the feed launches since the last call found (synchronises `stream`), and clears it
+int sdrm_feed_status(sdrm_engine* e, void* stream) {
+  if (!e) return SDRM_ERR_ARG;
+  unsigned flag = 0;
+  HIP_TRY(e, hipMemcpyAsync(&flag, e->feed_flag, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+  if (!flag) return SDRM_OK;
+  HIP_TRY(e, hipMemsetAsync(e->feed_flag, 0, sizeof(flag), (hipStream_t)stream));
+  std::string msg = "sdrm_csr_rows_to_dense:";
+  if (flag & FEED_BAD_ROW) msg += " a row id outside [0, n_rows) (its output row is zero);";
+  if (flag & FEED_BAD_PTR) msg += " an indptr pair that is negative or not ordered (its output row is zero);";
+  if (flag & FEED_BAD_COL) msg += " a column index outside [0, n_items) (that entry was skipped);";
+  return fail(e, SDRM_ERR_ARG, msg);
 }
 
 // ---------------------------------------------------------------------------------------------

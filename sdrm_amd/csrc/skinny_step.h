@@ -17,7 +17,9 @@
 //                   gradients (column sums in the dgrad epilogue) and the slope partials - written as ONE slab set per
 //                   work-group, which the tail reduces.  Neither dpre nor the embedding columns of U ever reach memory.
 // Stacked row order ("grouped by 16"): row(pass, user) = 48 * (user / 16) + 16 * pass + user % 16.
-// The step's time-embedding table B0tab = b0 + C0[t] comes from the previous step's tail (tail.h: k_tail_emb_tab).
+// The step's time-embedding table B0tab = b0 + C0[t]: with T <= 128 the forward makes its users' rows itself from the padded copies
+// WeP / W0eP the tail keeps current (`intab`, no k_emb_tables launch); longer embeddings do not fit that LDS image and take the
+// table from a k_emb_tables launch in front of the forward (sdrm_hip.hip: ensure_tables - one more launch per step).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -23,6 +24,13 @@ def _ptr(t):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _ParamSpan:
+    """What torch.as_tensor needs to wrap foreign device memory: the engine's flat parameter vector."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 class Engine:
@@ -49,13 +57,33 @@ class Engine:
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.gradient_buckets = 2 if os.environ.get("SDRM_AR_BUCKETS", "1").strip() == "2" else 1   # of train_step_sharded
         self._keepalive = None
+        self._n_views = 0                 # spans handed out by params_view() that some tensor's storage still holds
+        self._close_pending = False
 
     # ------------------------------------------------------------------ plumbing
     def close(self):
-        if getattr(self, "_h", None):
-            torch.cuda.synchronize(self.device)
-            self.lib.sdrm_destroy(self._h)
-            self._h = C.c_void_p()
+        """Frees the engine - unless tensors returned by `params_view()` (an SDRM's `parameters()`) are still alive: they alias the
+        master vector sdrm_destroy would free, so the handle then stays allocated (and unused) until the last of them is gone.
+        Such a tensor of a closed engine keeps reading the parameters as they were at close()."""
+        if not getattr(self, "_h", None):
+            return
+        if self._n_views > 0:
+            self._close_pending = True
+            return
+        torch.cuda.synchronize(self.device)
+        self.lib.sdrm_destroy(self._h)
+        self._h = C.c_void_p()
+        self._close_pending = False
+
+    @property
+    def closed(self):
+        return not getattr(self, "_h", None)
+
+    @staticmethod
+    def _view_released(eng):
+        eng._n_views -= 1
+        if eng._close_pending and eng._n_views <= 0:
+            eng.close()
 
     def __del__(self):
         try:
@@ -127,13 +155,12 @@ class Engine:
     def params_view(self):
         """The live parameters in place (sdrm_params_ptr): a [P] float32 tensor that ALIASES the engine's master vector - it follows
         every train step without a copy.  Read it; do not write through it (the kernels read compute copies of it)."""
-        class _Span:   # what torch.as_tensor needs to wrap foreign device memory
-            pass
-        span = _Span()
-        span.__cuda_array_interface__ = {"shape": (self.P,), "typestr": "<f4", "data": (int(self.lib.sdrm_params_ptr(self._h)), False), "version": 2}
-        t = torch.as_tensor(span, device=self.device)
-        t._sdrm_owner = self   # the memory lives as long as the engine
-        return t
+        span = _ParamSpan(int(self.lib.sdrm_params_ptr(self._h)), self.P)
+        # torch keeps `span` for the lifetime of the storage it wraps (every view / slice / detach() of the tensor shares that
+        # storage); the finalizer holds the engine until the span dies, and close() defers sdrm_destroy while any span is alive
+        self._n_views += 1
+        weakref.finalize(span, Engine._view_released, self).atexit = False
+        return torch.as_tensor(span, device=self.device)
 
     def philox_draws(self, seed, purpose, step, rows, quads, row0=0, with_bits=True):
         """Test hook (sdrm_debug_philox_draws): the device generator's normals [rows, 4 * quads] and the low three bits of its
@@ -428,21 +455,28 @@ class Engine:
         return (torch.from_numpy(m.indptr.astype(np.int64)).to(self.device),
                 torch.from_numpy(m.indices.astype(np.int32)).to(self.device), data, m.shape)
 
-    def csr_rows_to_dense(self, csr_dev, rows=None, row0=0, b=None):
+    def csr_rows_to_dense(self, csr_dev, rows=None, row0=0, b=None, check=True):
         """dataloaders.py:46-79 + `.to_dense()` (train_SDRM.py:323) on the device: dense float32 [b, n_items] of the rows
-        `rows` (int64 tensor, e.g. a slice of the epoch permutation) or row0 .. row0+b-1 of a `csr_to_device` matrix."""
+        `rows` (int64 tensor, e.g. a slice of the epoch permutation) or row0 .. row0+b-1 of a `csr_to_device` matrix.
+        Row ids and column indices are range-checked ON THE DEVICE (an offending row / entry stays zero, never a stray store);
+        `check=True` reads the verdict back at once (one stream sync) and raises, `check=False` leaves it to a later
+        `feed_status()` - what an epoch loop wants (`pipeline.DeviceFeed` asks once per epoch)."""
         indptr, indices, data, (n_rows, n_items) = csr_dev
         if rows is not None:
             rows = self._dev(rows, torch.int64)
             b = rows.numel()
-            if b and (int(rows.min()) < 0 or int(rows.max()) >= n_rows):
-                raise SdrmError("csr_rows_to_dense: row id outside the matrix")
-        elif b is None or row0 < 0 or row0 + b > n_rows:
-            raise SdrmError("csr_rows_to_dense: row range outside the matrix")
+        elif b is None:
+            raise SdrmError("csr_rows_to_dense: give `rows` or `row0` and `b`")
         out = torch.empty(b, n_items, dtype=torch.float32, device=self.device)
-        self._check(self.lib.sdrm_csr_rows_to_dense(self._h, _ptr(indptr), _ptr(indices), _ptr(data), _ptr(rows), int(row0), int(b),
-                                                    int(n_items), _ptr(out), _stream()), "sdrm_csr_rows_to_dense")
+        self._check(self.lib.sdrm_csr_rows_to_dense(self._h, _ptr(indptr), _ptr(indices), _ptr(data), int(n_rows), _ptr(rows), int(row0),
+                                                    int(b), int(n_items), _ptr(out), _stream()), "sdrm_csr_rows_to_dense")
+        if check:
+            self.feed_status()
         return out
+
+    def feed_status(self):
+        """Raises if any `csr_rows_to_dense` launch since the last call met a row id / column index outside the matrix."""
+        self._check(self.lib.sdrm_feed_status(self._h, _stream()), "sdrm_feed_status")
 
     def rank_metrics(self, scores, heldout, train=None, ks=(1, 3, 5, 10, 20, 50)):
         """utilities.py:116-171 on the device: (recall[nk,U], ndcg[nk,U]) float64 device tensors for a score matrix

@@ -71,8 +71,9 @@ class DeviceFeed:
     def __iter__(self):
         perm = torch.randperm(self.n_rows, generator=self.gen).to(self.engine.device)
         for lo in range(0, self.n_rows, self.batch_size):
-            x = self.engine.csr_rows_to_dense(self.csr, rows=perm[lo:lo + self.batch_size])
+            x = self.engine.csr_rows_to_dense(self.csr, rows=perm[lo:lo + self.batch_size], check=False)
             yield x, x
+        self.engine.feed_status()   # the device-side range checks of the epoch's batches, read once (one sync per epoch)
 
 
 def equal_sparsity(raw, sparsity: float, engine) -> np.ndarray:

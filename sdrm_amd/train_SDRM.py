@@ -51,14 +51,40 @@ class EngineParameter(torch.Tensor):
     stepping these tensors would change nothing the net computes with (the reference's callers never do: they only call
     `train_SDRM`, `diff_net.eval()` and `diff_net.forward`, hyperparameter_search.py:53,67,78)."""
 
+    _HARMLESS = frozenset({"requires_grad_", "retain_grad", "share_memory_", "register_hook"})   # end in "_" / mutate nothing of the data
+
+    @staticmethod
+    def _writes(func, name):
+        """True when `func` writes through one of its tensor arguments: by its schema where it has one (aten overloads carry alias
+        info), else by torch's naming rule for in-place methods and the in-place operator dunders."""
+        if name in EngineParameter._HARMLESS:
+            return False
+        schema = getattr(func, "_schema", None)
+        if schema is not None:
+            return bool(schema.is_mutable)
+        return (name.endswith("_") and not name.endswith("__")) or name in ("__setitem__", "__iadd__", "__isub__", "__imul__", "__itruediv__",
+                                                                            "__ifloordiv__", "__imod__", "__ipow__", "__iand__", "__ior__",
+                                                                            "__ixor__", "__ilshift__", "__irshift__", "__imatmul__")
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         name = getattr(func, "__name__", "")
-        if (name.endswith("_") and not name.endswith("__")) or name in ("__setitem__", "__iadd__", "__isub__", "__imul__", "__itruediv__"):
+        outs = (kwargs or {}).get("out")
+        outs = outs if isinstance(outs, (tuple, list)) else (outs,)
+        if cls._writes(func, name) or any(isinstance(o, EngineParameter) for o in outs):
             raise SdrmError(f"in-place {name} on a parameter of an engine-backed SDRM: its parameters are updated by the engine's train "
                             "step (train_SDRM / Engine.train_step) or replaced with load_state_dict()")
         with torch._C.DisableTorchFunctionSubclass():
             out = func(*args, **(kwargs or {}))
+        # a result that shares the parameter's storage (`.data`, `.detach()`, a view, a slice) is a parameter view too: it keeps the
+        # guard, so `p.data.add_()` / `p.detach().mul_()` / `p.view(-1).zero_()` raise like `p.add_()` does
+        if name != "as_subclass" and isinstance(out, torch.Tensor) and not isinstance(out, EngineParameter):   # (as_subclass: the caller's explicit way out)
+            src = next((a for a in args if isinstance(a, EngineParameter)), None)
+            try:
+                if src is not None and out.device == src.device and out.untyped_storage().data_ptr() == src.untyped_storage().data_ptr():
+                    out = out.as_subclass(EngineParameter)
+            except RuntimeError:
+                pass   # (a result without storage, e.g. a meta / sparse tensor: not a view of the parameters)
         return out
 
 
@@ -144,13 +170,18 @@ class SDRM:
         and torch.optim refuses them when it is built (they are views, not leaves) instead of silently training a copy."""
         flat, off = self._flat(), 0
         live = self._engine is not None
-        if live:   # views of a leaf that requires grad: torch.optim refuses them at construction ("can't optimize a non-leaf Tensor")
-            flat = flat.requires_grad_(True)
-        for name, shp in ((n, synth.param_shapes(self.L, self.W, self.T, self.H)[n]) for n in synth.param_names(self.H)):
-            k = int(np.prod(shp))
-            v = flat[off:off + k].reshape(shp)
-            yield name, (v.as_subclass(EngineParameter) if live else v)
-            off += k
+        out = []
+        # views of a leaf that requires grad: torch.optim refuses them at construction ("can't optimize a non-leaf Tensor") - built
+        # under enable_grad(), so that holds for a caller inside torch.no_grad() as well (evaluation code usually is)
+        with torch.enable_grad():
+            if live:
+                flat = flat.requires_grad_(True)
+            for name, shp in ((n, synth.param_shapes(self.L, self.W, self.T, self.H)[n]) for n in synth.param_names(self.H)):
+                k = int(np.prod(shp))
+                v = flat[off:off + k].reshape(shp)
+                out.append((name, (v.as_subclass(EngineParameter) if live else v)))
+                off += k
+        return iter(out)
 
     def parameters(self):
         return [p for _, p in self.named_parameters()]

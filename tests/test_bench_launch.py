@@ -33,7 +33,7 @@ def test_rank_command_is_the_drivers_form():
     assert not launch.inside_launcher({}) and launch.inside_launcher({"RANK": "0"}) and launch.inside_launcher({"WORLD_SIZE": "2"})
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [1, 2, 8])
 def test_bench_as_a_plain_command(gpus):
     r = run_bench("--gpus", str(gpus), "--steps", "12", "--warmup", "2", "--windows", "2", "--stub-engine")
     assert r.returncode == 0, r.stderr[-2000:]
@@ -50,3 +50,17 @@ def test_a_failing_rank_ends_the_command_nonzero():
     r = run_bench("--gpus", "2", "--steps", "4", "--stub-engine", env_extra={"SDRM_BENCH_TEST_FAIL_RANK": "1"})
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.parametrize("hook", ["SDRM_BENCH_TEST_FAIL_RANK", "SDRM_BENCH_TEST_FAIL_RANK_LATE"])
+def test_rank_5_of_8_failing_ends_the_command_nonzero_in_time(hook):
+    """the first real 8-rank run must not be the first time the launcher sees eight ranks.  Rank 5 dies before the
+    rendezvous (its peers wait in init_process_group) or after it (its peers sit in the first collective): either way the
+    command ends non-zero, without a JSON line, long before the 180 s communicator watchdog."""
+    import time
+    t0 = time.time()
+    r = run_bench("--gpus", "8", "--steps", "4", "--warmup", "1", "--windows", "1", "--stub-engine", env_extra={hook: "5"}, timeout=170)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank 5 asked to fail" in r.stderr
+    assert time.time() - t0 < 150

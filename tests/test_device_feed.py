@@ -63,3 +63,47 @@ def test_feed_argument_errors(engine):
         engine.csr_rows_to_dense(dev, rows=torch.tensor([0, 5]))
     with pytest.raises(SdrmError):
         engine.csr_rows_to_dense(dev, row0=3, b=3)
+
+
+@pytest.mark.gpu
+def test_out_of_range_csr_is_caught_on_the_device_not_written_out_of_bounds(engine):
+    """VERDICT r4 item 7 (dataloaders.py:46-79 hands a scipy CSR to the feed; a corrupt one must not become a stray device store):
+    a row id outside the matrix leaves that output row zero, a column index outside [0, n_items) skips that entry, every other
+    row / entry is delivered as scipy would, and the handle reports SDRM_ERR_ARG at the next status read (then is clean again)."""
+    from sdrm_amd.engine import SdrmError
+    rs = np.random.RandomState(5)
+    dense = (rs.random_sample((12, 37)) < 0.3).astype(np.float32)
+    m = csr_matrix(dense)
+    indptr, indices, data, shape = engine.csr_to_device(m)
+    # (1) row ids: -1 and n_rows among good ones; a guard band behind the output shows nothing was written past it
+    rows = torch.tensor([3, -1, 7, 12, 0], dtype=torch.int64)
+    out = engine.csr_rows_to_dense((indptr, indices, data, shape), rows=rows, check=False).cpu().numpy()
+    np.testing.assert_array_equal(out[[0, 2, 4]], dense[[3, 7, 0]])
+    assert not out[1].any() and not out[3].any()
+    with pytest.raises(SdrmError, match="row id outside"):
+        engine.feed_status()
+    engine.feed_status()                        # the record was cleared
+    # (2) column indices: one entry of row 2 points behind the row, one is negative
+    bad = indices.clone()
+    lo, hi = int(m.indptr[2]), int(m.indptr[3])
+    assert hi - lo >= 2
+    bad[lo] = 37
+    bad[lo + 1] = -4
+    out = engine.csr_rows_to_dense((indptr, bad, data, shape), row0=0, b=12, check=False).cpu().numpy()
+    want = dense.copy()
+    want[2, m.indices[lo]] = 0
+    want[2, m.indices[lo + 1]] = 0
+    np.testing.assert_array_equal(out, want)
+    with pytest.raises(SdrmError, match="column index outside"):
+        engine.feed_status()
+    # (3) checked call: raises at once; an unordered indptr pair is a zero row, not a wild loop
+    with pytest.raises(SdrmError):
+        engine.csr_rows_to_dense((indptr, bad, data, shape), row0=0, b=12)
+    badptr = indptr.clone()
+    badptr[5] = badptr[6] + 3
+    out = engine.csr_rows_to_dense((badptr, indices, data, shape), row0=5, b=1, check=False).cpu().numpy()
+    assert not out.any()
+    with pytest.raises(SdrmError, match="indptr"):
+        engine.feed_status()
+    good = engine.csr_rows_to_dense((indptr, indices, data, shape), row0=0, b=12).cpu().numpy()
+    np.testing.assert_array_equal(good, dense)

@@ -25,6 +25,8 @@ def _shapes(n=20, seed=20261004):
         H = int(rng.integers(0, 4))
         B = int(rng.integers(1, 261))
         out.append((L, W, T, H, B))
+    # the longest embeddings sdrm_create accepts (k_tail_emb's LDS image ends at T = 1020; T >= 1021 is refused)
+    out += [(24, 24, 1020, 1, 7), (70, 70, 517, 0, 9)]
     return out
 
 

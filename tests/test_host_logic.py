@@ -76,8 +76,25 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     h = ctypes.c_void_p()
     assert lib.sdrm_create(0, 8, 5, 1, 4, 0, ctypes.byref(h)) == -2          # SDRM_ERR_SHAPE
     assert lib.sdrm_create(8, 8, 5, 1, 4, 0, None) == -1                     # SDRM_ERR_ARG
+    # k_tail_emb's LDS image grows with T and passes 160 KB at T = 1021: refused up front, not at the first launch
+    assert lib.sdrm_create(8, 8, 1021, 1, 4, 0, ctypes.byref(h)) == -2 and not h.value
+    assert lib.sdrm_create(8, 8, 1024, 1, 4, 0, ctypes.byref(h)) == -2 and not h.value
     assert lib.sdrm_param_count(None) == -1
     assert lib.sdrm_destroy(None) == -1
+
+
+def test_device_check_refuses_anything_but_the_chip_the_grids_are_sized_for():
+    """the one-round launches (one work-group per CU) and the XCD mapping assume a gfx950 with 256 compute
+    units; sdrm_create asks this pure function (hipDeviceProp_t::gcnArchName, multiProcessorCount) and refuses the rest."""
+    lib = _lib.load()
+    assert lib.sdrm_debug_device_check(b"gfx950:sramecc+:xnack-", 256) == 0
+    assert lib.sdrm_debug_device_check(b"gfx950", 256) == 0
+    for arch, cus in ((b"gfx950:sramecc+:xnack-", 32), (b"gfx950", 128), (b"gfx950", 304), (b"gfx942:sramecc+:xnack-", 304),
+                      (b"gfx942", 256), (b"gfx9500", 256), (b"gfx90a", 104), (b"", 256)):
+        assert lib.sdrm_debug_device_check(arch, cus) == -7, (arch, cus)      # SDRM_ERR_DEVICE
+    assert lib.sdrm_debug_device_check(None, 256) == -1
+    assert _lib.STATUS[-7] == "SDRM_ERR_DEVICE"
+    assert b"256 compute units" in lib.sdrm_build_info()
 
 
 @pytest.mark.parametrize("rows,n_out,k_in", [(24576, 352, 448), (24576, 352, 352), (1664, 832, 928), (1664, 832, 832),

@@ -101,6 +101,56 @@ def test_parameters_are_live_views_and_refuse_writes():
         net.cpu()
 
 
+def test_parameter_views_survive_an_engine_rebuild():
+    """`train_SDRM` (batch <= 1024) then `sample_ddpm(n_sample=5429)` rebuilds the engine with more rows.  Tensors
+    taken from `parameters()` before that alias the OLD engine's master vector: it must stay allocated until they are gone (reads
+    give the parameters as they were at the rebuild - never freed memory), and be freed then."""
+    import gc
+    import sdrm_amd.train_SDRM as ts
+    net = ts.SDRM(16, 6, 24, 1, max_rows=8).cuda()
+    old = net.engine(8)
+    old.train_step(torch.randn(8, 16, device="cuda"), 1e-2, seed=1, step=0)
+    held = net.parameters()
+    snap = [p.as_subclass(torch.Tensor).clone() for p in held]
+    new = net.engine(64)                                   # rows > max_rows: a new handle, the old one closed
+    assert new is not old and not old.closed               # ... but deferred: `held` still aliases its memory
+    new.train_step(torch.randn(64, 16, device="cuda"), 1e-2, seed=1, step=1)
+    filler = [torch.full((1 << 20,), 7.0, device="cuda") for _ in range(4)]   # would land in freed memory, were it freed
+    torch.cuda.synchronize()
+    for p, q in zip(held, snap):
+        assert torch.equal(p.as_subclass(torch.Tensor), q)
+    assert not torch.equal(torch.cat([q.reshape(-1) for q in snap]), new.get_params())   # the new engine has moved on
+    del held, p, filler
+    gc.collect()
+    assert old.closed                                      # the last view is gone: the deferred sdrm_destroy ran
+    fresh = net.parameters()
+    assert torch.equal(torch.cat([p.as_subclass(torch.Tensor).reshape(-1) for p in fresh]), new.get_params())
+
+
+def test_parameter_write_guard_covers_aliases_and_no_grad():
+    """`.data`, `.detach()` and views of a parameter share its storage and keep the guard; parameters handed out under
+    torch.no_grad() are still non-leaf (torch.optim refuses them); `requires_grad_` is not a write."""
+    import sdrm_amd.train_SDRM as ts
+    from sdrm_amd.engine import SdrmError
+    net = ts.SDRM(16, 6, 24, 1).cuda()
+    eng = net.engine(8)
+    with torch.no_grad():
+        params = dict(net.named_parameters())
+        with pytest.raises(ValueError, match="non-leaf"):
+            torch.optim.Adam(list(params.values()), lr=1e-3)
+    p = params["dnn.0.bias"]
+    before = eng.get_params().clone()
+    for write in (lambda: p.data.add_(1.0), lambda: p.detach().mul_(2.0), lambda: p.view(-1).zero_(), lambda: p[:2].fill_(3.0),
+                  lambda: p.__setitem__(0, 1.0), lambda: torch.add(p, 1.0, out=p), lambda: p.copy_(torch.zeros_like(p))):
+        with pytest.raises((SdrmError, RuntimeError)):
+            write()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.get_params(), before)           # nothing got through
+    p.requires_grad_(True)                                 # harmless: no data is written (not refused as an in-place write)
+    assert float((p.detach() + 1).sum()) == float(p.as_subclass(torch.Tensor).sum() + p.numel())   # reads through aliases are ordinary ops
+    assert type(p.detach().clone()) is torch.Tensor        # a copy is the caller's own tensor
+
+
 def test_cache_latents_matches_per_batch_encoding(tmp_path):
     """encoding the feed once gives the same trained eps-net as encoding per batch."""
     import sdrm_amd.train_SDRM as ts
