@@ -111,7 +111,7 @@ def test_parameter_views_survive_an_engine_rebuild():
     old = net.engine(8)
     old.train_step(torch.randn(8, 16, device="cuda"), 1e-2, seed=1, step=0)
     held = net.parameters()
-    snap = [p.as_subclass(torch.Tensor).clone() for p in held]
+    snap = [p.detach().clone() for p in held]              # (detached: a clone WITH autograd history would itself keep the base alive)
     new = net.engine(64)                                   # rows > max_rows: a new handle, the old one closed
     assert new is not old and not old.closed               # ... but deferred: `held` still aliases its memory
     new.train_step(torch.randn(64, 16, device="cuda"), 1e-2, seed=1, step=1)
@@ -120,7 +120,7 @@ def test_parameter_views_survive_an_engine_rebuild():
     for p, q in zip(held, snap):
         assert torch.equal(p.as_subclass(torch.Tensor), q)
     assert not torch.equal(torch.cat([q.reshape(-1) for q in snap]), new.get_params())   # the new engine has moved on
-    del held, p, filler
+    del held, p, q, filler
     gc.collect()
     assert old.closed                                      # the last view is gone: the deferred sdrm_destroy ran
     fresh = net.parameters()
