@@ -40,11 +40,18 @@ int sdrm_debug_set_nt32_rows(sdrm_engine* e, int max_rows, int max_rows_train);
 int sdrm_debug_set_skinny(sdrm_engine* e, int on);
 /* Row-owned train forward (csrc/rowchain.h: staging, every layer and the loss partial sums of a 96-row group of stacked rows in
  * ONE work-group per CU; nets with L == W and a padded width of 128..352): 0 never, 1 (default) when the batch fills whole
- * rounds of the chip (at least 216 groups of 32 users, the last round at least five sixths full), 2 whenever the net allows
+ * rounds of the chip (one round: at least 154 groups of 32 users; more: the last round at least five sixths full), 2 whenever the net allows
  * (tests); also env SDRM_ROWCHAIN.  A forced tile (sdrm_debug_set_tile) switches it off.  Results agree with the per-layer path
  * to fp32 summation order; the stacked rows of that step are in the GROUPED order (elementwise.h), which sdrm_get_train_outputs
  * / sdrm_get_preacts undo.  Refused between sdrm_train_backward_begin and _finish; drops a pending train forward. */
 int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
+/* The row-owned train step on 48-row work-groups (csrc/rows48.h: the P, S, Q rows of 16 users per work-group through staging,
+ * every layer and the loss sums, then through the loss seeds and every layer's input gradient; the nets of the row-owned forward):
+ * 0 never, 1 (default) when the batch's 16-user groups fill most of one round of the chip (176..256 groups: 2801..4096 users) and
+ * the 96-row kernels do not take the batch, 2 whenever the net allows (tests); also env SDRM_ROWS48.  sdrm_debug_set_rowchain(e, 2)
+ * and a forced tile take precedence.  The stacked rows of such a step are grouped by 16 users (elementwise.h).  Refused between
+ * sdrm_train_backward_begin and _finish; drops a pending train forward. */
+int sdrm_debug_set_rows48(sdrm_engine* e, int mode);
 /* Strip-owned weight gradients (csrc/wgrad2.h: every weight gradient of a step in one balanced round of one work-group per CU,
  * bias gradients from the ones column of the layer inputs) behind the row-owned forward: 1 (default) on, 0 the batched 64x64-tile
  * split-K launch; also env SDRM_WGRAD_STRIPS.  Takes effect with the next backward. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "sdrm_debug_set_fused_reverse": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_skinny": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_rowchain": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_rows48": (c_int, [c_void_p, c_int]),
     "sdrm_debug_rowchain_available": (c_int, [c_void_p]),
     "sdrm_debug_set_wgrad_strips": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_dgrad_rows": (c_int, [c_void_p, c_int]),

@@ -109,7 +109,7 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
 // still to come, and takes its share of the 3 * CT pre-activation quads - spread over all of them: in the last two K-steps alone
 // they are a 35 MB burst chip-wide, more than HBM delivers in that time
 // LIGHT: K-step KS - 1 is the compact one (its G fragments, fetched by K-step KS - 3, come from `goffl`)
-template <int CT, int KS, int PEEL, bool LIGHT, int J>
+template <int CT, int KS, int PEEL, bool LIGHT, int J, int NCT = 2 * CT>
 __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc Gw, const uint32_t (&goff)[3],
                                         const uint32_t (&goffl)[3], brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw,
                                         const uint32_t (&poff)[3]) {
@@ -119,23 +119,29 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
     constexpr int MODE = !LIGHT ? RC_PLAIN : (K == KS - 3 ? RC_NEXT_LIGHT : (K == KS - 1 ? RC_LIGHT : RC_PLAIN));
     constexpr int NA = K + 2 < KS ? 3 : 0, NB = K + 1 < KS ? CT : 0;
     constexpr int PRE0 = J * NQ / PEEL, NPRE = (J + 1) * NQ / PEEL - PRE0;
-    constexpr uint32_t WSTEP = 2u * CT * 1024u;
+    constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;
     dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf,
                                                   (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
-    dr_peel<CT, KS, PEEL, LIGHT, J + 1>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+    dr_peel<CT, KS, PEEL, LIGHT, J + 1, NCT>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   }
 }
 
-// one layer for the work-group's 96 rows (block index g); `red`: four floats of LDS
-template <int CT, bool LIGHT>
+// one layer for the work-group's ROWS stacked rows (block index g); `red`: four floats of LDS.
+// ROWS = 96 (this file's kernels: 32 users, waves as 2 x 2, CT column tiles each) or 48 (rows48.h: 16 users, the four waves side
+// by side, CT = ceil(NCT / 4) column tiles each - the last wave's tiles beyond the NCT real ones are computed and dropped).
+template <int CT, bool LIGHT, int ROWS = RC_ROWS, int NCT = 2 * CT>
 __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red) {
-  constexpr int NP = 32 * CT, NCT = 2 * CT, KS = NP / 16, NQ = 3 * CT;
+  constexpr int KS = NCT, NQ = 3 * CT;
+  constexpr int WC = 4 / (ROWS / 48);             // waves side by side along the columns
+  constexpr bool ALLV = CT * WC == NCT;           // every tile of every wave is a real one
+  static_assert(ROWS == 48 || ROWS == 96, "a work-group owns the P, S, Q rows of 16 or 32 users");
+  static_assert(CT * WC >= NCT && (CT - 1) * WC < NCT, "per-wave column tiles do not cover the layer");
   static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int li = lane & 15, lq = lane >> 4;
-  const size_t grow0 = (size_t)RC_ROWS * g;
+  const size_t grow0 = (size_t)ROWS * g;
   const uint32_t lane16 = 16u * (uint32_t)lane;
 #ifdef DR_STAMPS
   unsigned long long st_[8] = {0};
@@ -153,9 +159,9 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
     poff[rt] = (uint32_t)((row * a.ldp + 16 * CT * wc + 4 * lq) * 4);
     ooff[rt] = (uint32_t)((row * a.ldo + 16 * CT * wc + 4 * lq) * 4);
   }
-  const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(RC_ROWS * a.ldg * 4));
+  const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(ROWS * a.ldg * 4));
   const brsrc Wf = make_brsrc(a.WfT + (size_t)(CT * wc) * 256, (uint32_t)((KS * NCT - CT * wc) * 1024));
-  const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(RC_ROWS * a.ldp * 4));
+  const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
   gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
   const float slope = *a.slope;
 
@@ -190,7 +196,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
     dr_kstep<CT, 3, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
   }
   DR_STAMP(2);
-  dr_peel<CT, KS, PEEL, LIGHT, 0>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+  dr_peel<CT, KS, PEEL, LIGHT, 0, NCT>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   DR_STAMP(3);
   rc_acc_settle<CT>(acc);
   // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
@@ -199,6 +205,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
+      if (!ALLV && CT * wc + ct >= NCT) continue;   // (wave-uniform) a tile beyond the layer's columns: what it computed is dropped
       const f32x4 p = pq[rt * CT + ct];
       f32x4 v = acc[rt][ct];
       asm("" : "+v"(v));   // one copy out of the accumulator registers, every use below reads it

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(256) void k_loss_seed(const SeedArgs a) {
   const float cV = (float)(-(0.5 * (A + C) / (den * den)) * 2.0 / (N - 1.0));
   const float rbar = (float)Rbar;
   // items: user slots (three rows each), then the padding rows behind them (one row each)
-  const int nslots = a.grouped ? RC_USERS * ((a.B + RC_USERS - 1) / RC_USERS) : a.B;
+  const int gu = a.grouped == 2 ? 16 : RC_USERS;   // users per group of the grouped orders
+  const int nslots = a.grouped ? gu * ((a.B + gu - 1) / gu) : a.B;
   const int ntail = a.MP - 3 * nslots;
   const size_t total = (size_t)(nslots + ntail) * QP;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);

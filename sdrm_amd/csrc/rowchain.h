@@ -188,7 +188,8 @@ __device__ __forceinline__ void rc_acc_settle(f32x4 (&acc)[3][CT]) {
 // compact fragments (one float per lane: k = 16 ks + lane group; `anext` is that address); RC_LIGHT - this IS the compact K-step:
 // only the first MFMA of every tile is issued (its four lane groups hold the four real k), and nothing is fetched behind it.
 enum { RC_PLAIN = 0, RC_NEXT_LIGHT = 1, RC_LIGHT = 2 };
-template <int CT, int LDA, int NS, bool STREAM, bool NT, int MODE = RC_PLAIN>
+// RTS: rows between two of the wave's row tiles in the LDS tile (the users of a group: 32 here, 16 in rows48.h)
+template <int CT, int LDA, int NS, bool STREAM, bool NT, int MODE = RC_PLAIN, int RTS = RC_USERS>
 __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[3], const f32x4 (&bc)[CT], f32x4 (&an)[3],
                                          f32x4 (&bn)[CT], brsrc wres, uint32_t wnext, uint32_t lane16, uint32_t anext,
                                          const float* __restrict__ Act, brsrc sres, RcStream& sw) {
@@ -223,12 +224,13 @@ __device__ __forceinline__ void rc_kstep(f32x4 (&acc)[3][CT], const f32x4 (&ac)[
         if (!(RC_DIAG & 4)) {
           uint32_t ao = anext;
           asm volatile("" : "+v"(ao));
-          if (MODE == RC_NEXT_LIGHT) an[p - P_A][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
-          else an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RC_USERS * LDA * 4);
+          if (MODE == RC_NEXT_LIGHT) an[p - P_A][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RTS * LDA * 4);
+          else an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * RTS * LDA * 4);
         }
       } else {
         // tile stream, chunk q: LDS read, then (NS pieces later) the HBM store
-        const int k = p - P_S, ph = k / NS, q = k % NS;
+        constexpr int NSD = NS > 0 ? NS : 1;   // (NS = 0: no stream pieces; the branch is dead but compiled)
+        const int k = p - P_S, ph = k / NSD, q = k % NSD;
         if (!(RC_DIAG & 1)) {
           f32x4& v = q == 0 ? sv0 : sv1;
           uint32_t& so = q == 0 ? so0 : so1;

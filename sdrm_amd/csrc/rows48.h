@@ -1,0 +1,392 @@
+// The row-owned train step for batches that do NOT fill the chip with 96-row work-groups (rowchain.h, dgrad_rows.h): the same
+// ownership at half the height.  ONE work-group owns 48 stacked rows - the P, S and Q rows of 16 users (train_SDRM.py:331-333) -
+// through staging (q_sample + three dropout masks, :326-331 / :100), ALL H + 2 layers (:97-103) and the loss partial sums
+// (:191-199) in the forward, and through the loss value, the gradient seeds and every layer's input gradient in the backward
+// (:336).  A batch of 4096 users (the 2-GPU shard of the 8192 batch) is 256 such work-groups - one round of the chip - where the
+// 96-row kernels would leave half the CUs idle and the per-layer path runs eleven launches.
+//
+// What changes against the 96-row kernels:
+//   * the four waves stand SIDE BY SIDE along the columns: wave w owns all three row tiles (P, S, Q of the same 16 users: the out
+//     layer's loss sums still come straight out of one lane's accumulators) and the column tiles [CW w, CW w + CW), CW =
+//     ceil(NCT / 4) of the layer's NCT = NP / 16 tiles (6 at NP = 352, where the last wave has four real tiles: its two tiles
+//     beyond the layer are multiplied - operands out of range read as zero - and dropped; the other waves set the time anyway);
+//   * every wave fetches DIFFERENT weight fragments (in the 96-row kernel the two row halves fetch the same ones): per CU the same
+//     bytes per cycle from L1, twice the bytes per flop from L2 (10.4 B per cycle and CU, inside what every kernel here sustains);
+//   * the 48 x NP tile is 69 KB of LDS (two work-groups fit a CU: batches between 4096 and 6912 users run two rounds' worth of
+//     work-groups side by side) and is NOT streamed to HBM while a layer multiplies: the layer input (U, then the activations) is
+//     stored straight from registers by the staging / the epilogue that produces it - half the rows make half the burst;
+//   * stacked row order "grouped by 16" (elementwise.h, stacked_row(2, ..)): row = 48 (user / 16) + 16 pass + user % 16, the order
+//     the narrow nets' kernels use.
+// K-steps, pipeline pieces, asm MFMAs with tied accumulators, swapped operands (a lane holds four consecutive COLUMNS of a row),
+// fragment-packed weights with the compact last K-step: rowchain.h's, through the same rc_kstep / dr_kstep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dgrad_rows.h"
+#include "rowchain.h"
+
+namespace sdrm {
+
+constexpr int R48_USERS = 16;
+constexpr int R48_ROWS = 3 * R48_USERS;
+
+template <int CT>
+struct Rows48Cfg {
+  static constexpr int NP = 32 * CT, NCT = 2 * CT, CW = (NCT + 3) / 4, KS = NP / 16, QP = NP / 4, LDA = rc_lda(NP);
+  static constexpr int NQ = (QP + 15) / 16;   // column quads per staging thread (16 quad lanes per user)
+  static constexpr size_t LDS_BYTES = (size_t)R48_ROWS * LDA * 4 + 512;
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups share a CU's LDS");
+};
+
+// LIGHT: the weight copies' last K-step is compact (a.light; the host picks the instantiation).  Arguments: rowchain.h's.
+template <int CT, bool LIGHT = false>
+__global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a) {
+  typedef Rows48Cfg<CT> C;
+  constexpr int NP = C::NP, NCT = C::NCT, CW = C::CW, KS = C::KS, QP = C::QP, LDA = C::LDA, NQ = C::NQ, RT = 3;
+  constexpr bool ALLV = 4 * CW == NCT;
+  static_assert(KS % 2 == 0, "K-steps are taken in pairs");
+  __shared__ __attribute__((aligned(16))) float Act[R48_ROWS * LDA];
+  __shared__ int trow[R48_USERS];
+  __shared__ double red[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave = its column block
+  const int li = lane & 15, lq = lane >> 4;
+  const int g = blockIdx.x, u0 = R48_USERS * g;
+  const size_t grow0 = (size_t)R48_ROWS * g;   // first stacked row of this work-group
+
+  // ---------------------------------------------------------------- staging
+  if (tid < R48_USERS) {
+    const int usr = u0 + tid;
+    int t0 = 0;
+    if (usr < a.B) {
+      if (a.mode == 0) {
+        t0 = (int)a.t[usr];
+      } else {
+        const U4 w = philox4x32_10((uint32_t)(a.row0 + usr), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
+        t0 = 1 + (int)bounded(w.x, (uint32_t)a.T);
+      }
+      t0 = min(max(t0, 0), a.T);
+      a.tdev[usr] = t0;
+    }
+    trow[tid] = t0;
+  }
+  // thread -> (user tid >> 4, column quads (tid & 15) + 16 j): every x0 quad of the thread is requested before the first is used
+  const int su = tid >> 4, sq = tid & 15;
+  const int susr = u0 + su;
+  float4 xs[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int c = 4 * (sq + 16 * j);
+    xs[j] = (susr < a.B && c < a.L) ? load4_unpadded(a.x0, susr, c, a.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const brsrc ures = make_brsrc(a.U + grow0 * a.K0, (uint32_t)(R48_ROWS * a.K0 * 4));
+  {
+    // the time-embedding columns of U, temb[t] of the row's timestep (read by the layer-0 weight gradient only: they deliver
+    // M = dpre0^T * temb, tail.h; rows of users beyond the batch stay all-zero): the P, S and Q row of this thread's user
+    const int TPc = a.K0 - a.LPs;          // a multiple of 32 columns
+    const bool uin = susr < a.B;
+    const float* trow_p = a.tembP + (size_t)(uin ? trow[su] : 0) * TPc;
+    for (int c = 4 * sq; c < TPc; c += 64) {
+      const float4 te = uin ? *reinterpret_cast<const float4*>(trow_p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const f32x4 oh = {te.x, te.y, te.z, te.w};
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+        bstore4<true>(ures, (uint32_t)(((pass * R48_USERS + su) * a.K0 + a.LPs + c) * 4), 0u, oh);
+    }
+  }
+  {
+    const int tt = trow[su];
+    const float sa = a.sqrt_ab[tt], om = a.one_minus_ab[tt];
+    // PHILOX mode: the thread's NQ calls (one per column quad: two normal pairs and, in the low bits of word j, the three keep
+    // bits of column j) in ONE straight-line block (rowchain.h)
+    U4 rw[NQ];
+    if (a.mode != 0) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        rw[j] = philox4x32_10((uint32_t)(a.row0 + susr), (uint32_t)(sq + 16 * j), PURPOSE_TRAIN_ELEM, a.step, a.seed_lo, a.seed_hi);
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int c = 4 * (sq + 16 * j);
+      if (c >= NP) continue;   // (the sixteen quad lanes overhang the tile's last columns)
+      float vP[4] = {0.f, 0.f, 0.f, 0.f}, vS[4] = {0.f, 0.f, 0.f, 0.f}, vQ[4] = {0.f, 0.f, 0.f, 0.f};
+      if (susr < a.B && c < a.L) {
+        const float x_[4] = {xs[j].x, xs[j].y, xs[j].z, xs[j].w};
+        float e[4] = {0.f, 0.f, 0.f, 0.f};
+        uint32_t bits[4] = {0u, 0u, 0u, 0u};
+        if (a.mode != 0) {
+          const U4 w = rw[j];
+          box_muller(w.x, w.y, e[0], e[1]);
+          box_muller(w.z, w.w, e[2], e[3]);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) e[k] *= a.nd;
+          bits[0] = w.x; bits[1] = w.y; bits[2] = w.z; bits[3] = w.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (c + k < a.L) {
+            const size_t idx = (size_t)susr * a.L + c + k;
+            const float x = x_[k];
+            bool k1, k2, k3;
+            float ee;
+            if (a.mode == 0) {
+              ee = a.noise[idx];
+              const size_t BL = (size_t)a.B * a.L;
+              k1 = a.keep[idx] != 0; k2 = a.keep[BL + idx] != 0; k3 = a.keep[2 * BL + idx] != 0;
+            } else {
+              ee = e[k];
+              k1 = bits[k] & 1u; k2 = (bits[k] >> 1) & 1u; k3 = (bits[k] >> 2) & 1u;
+            }
+            vP[k] = k1 ? 2.f * (sa * x + om * ee) : 0.f;
+            vS[k] = k2 ? 2.f * x : 0.f;
+            vQ[k] = k3 ? 2.f * (x + MU * ee) : 0.f;
+          }
+        }
+      }
+      if (c == (a.ones_col & ~3)) {   // the ones column (a pad column: layer 0's weights are zero there)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == (a.ones_col & 3)) vP[k] = vS[k] = vQ[k] = 1.f;
+      }
+      const f32x4 fP = {vP[0], vP[1], vP[2], vP[3]}, fS = {vS[0], vS[1], vS[2], vS[3]}, fQ = {vQ[0], vQ[1], vQ[2], vQ[3]};
+      *reinterpret_cast<f32x4*>(Act + su * LDA + c) = fP;
+      *reinterpret_cast<f32x4*>(Act + (R48_USERS + su) * LDA + c) = fS;
+      *reinterpret_cast<f32x4*>(Act + (2 * R48_USERS + su) * LDA + c) = fQ;
+      // the layer-0 operand of the weight gradients, from the same registers (nobody reads it before them: non-temporal)
+      const uint32_t uo = (uint32_t)((su * a.K0 + c) * 4), up = (uint32_t)(R48_USERS * a.K0 * 4);
+      bstore4<true>(ures, uo, 0u, fP);
+      bstore4<true>(ures, uo + up, 0u, fS);
+      bstore4<true>(ures, uo + 2 * up, 0u, fQ);
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- layers
+  // wave wc: row tile rt = pass rt of the 16 users (tile rows 16 rt ..), column tiles CW wc ..; lane (li, lq) holds of tile (rt, ct)
+  // row 16 rt + li, columns 16 (CW wc + ct) + 4 lq .. + 3 (the transposed MFMA tile)
+  const float* abase = Act + li * LDA + 4 * lq;                  // + 16 rt LDA + 16 ks: A fragment reads
+  const uint32_t aoff = (uint32_t)((li * LDA + 4 * lq) * 4);     // the same as a byte offset into the tile
+  const uint32_t aoffl = (uint32_t)((li * LDA + lq) * 4);        // ... of the compact K-step's fragment (k = 16 ks + lq)
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  const int myrow = li;                            // + 16 rt: the lane's row of the tile; its user is u0 + li
+  const int mycol = 16 * CW * wc + 4 * lq;         // + 16 ct: the first of its four columns
+  float* __restrict__ otile = Act + myrow * LDA + mycol;
+  f32x4 acc[RT][CW];
+  f32x4 b0[CW], b1[CW];
+  f32x4 a0[RT], a1[RT];
+  f32x4 xq[CW];   // x0 at this lane's accumulator positions (loss sums), requested before the out layer's loop
+  RcStream sw{};  // (no tile stream here)
+  const brsrc nores = make_brsrc(a.U, 0u);
+
+  const int nlayers = a.H + 2;
+  for (int layer = 0; layer < nlayers; ++layer) {
+    const bool last = layer == nlayers - 1;
+    const brsrc Wf = make_brsrc((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)(CW * wc) * 256, (uint32_t)((KS * NCT - CW * wc) * 1024));
+    // accumulators start at the bias (layer 0: the row's own row of b0 + C0[t]); tiles beyond the layer read the slack behind it
+    {
+      const float* bsrc = layer == 0 ? a.B0tab + (size_t)trow[myrow] * a.ldtab : (last ? a.bo : a.bh);
+#pragma unroll
+      for (int ct = 0; ct < CW; ++ct) {
+        const bool tv = ALLV || CW * wc + ct < NCT;
+        const float4 bv = tv ? *reinterpret_cast<const float4*>(bsrc + mycol + 16 * ct) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = f32x4{bv.x, bv.y, bv.z, bv.w};
+      }
+    }
+    if (last) {
+      const int usr = u0 + myrow;
+#pragma unroll
+      for (int ct = 0; ct < CW; ++ct) {
+        const int col = mycol + 16 * ct;
+        const float4 x = (usr < a.B && col < a.L) ? load4_unpadded(a.x0, usr, col, a.L) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xq[ct] = f32x4{x.x, x.y, x.z, x.w};
+      }
+    }
+    // prologue: K-step 0's fragments
+#pragma unroll
+    for (int ct = 0; ct < CW; ++ct) b0[ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const f32x4*>(abase + rt * R48_USERS * LDA);
+    constexpr uint32_t WS = NCT * 1024;
+    rc_acc_begin<CW>(acc);
+#pragma unroll 1   // (a narrow net's few trips would be unrolled into the layer loop: code size for nothing)
+    for (uint32_t ks = 0; ks < (uint32_t)KS - 2; ks += 2) {
+      rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a0, b0, a1, b1, Wf, (ks + 1) * WS, lane16, aoff + 64u * (ks + 1), Act, nores, sw);
+      rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a1, b1, a0, b0, Wf, (ks + 2) * WS, lane16, aoff + 64u * (ks + 2), Act, nores, sw);
+    }
+    // the last pair: K-step KS - 1 may be the compact one (a.light: four real k in its sixteen)
+    if constexpr (LIGHT) {
+      rc_kstep<CW, LDA, 0, false, false, RC_NEXT_LIGHT, R48_USERS>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoffl + 64u * (KS - 1), Act, nores, sw);
+      rc_kstep<CW, LDA, 0, false, false, RC_LIGHT, R48_USERS>(acc, a1, b1, a0, b0, Wf, 0u, lane16, aoff, Act, nores, sw);
+    } else {
+      rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoff + 64u * (KS - 1), Act, nores, sw);
+      rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a1, b1, a0, b0, Wf, (KS - 2) * WS, lane16, aoff + 64u * (KS - 2), Act, nores, sw);   // past the end: a harmless re-read
+    }
+    rc_acc_settle<CW>(acc);
+    if (last) break;
+
+    // in-place epilogue: every wave is done reading the tile; then the pre-activations go to HBM as they are (read next by the
+    // dgrads), their PReLU into the tile - the next layer's input - and to HBM (act[layer]: what the weight gradients read)
+    __syncthreads();
+    {
+      const float slope = layer == 0 ? *a.slope0 : *a.slopeh;
+      gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
+      gchar* aw = uniform_gptr(a.act + (size_t)layer * a.pre_stride + grow0 * a.ldp);
+      const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);
+      const uint32_t prt = (uint32_t)(R48_USERS * a.ldp * 4);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CW; ++ct) {
+          if (!ALLV && CW * wc + ct >= NCT) continue;   // (wave-uniform) a tile beyond the layer's columns
+          const f32x4 v = acc[rt][ct];
+          const float4 h = make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
+          gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+          gstore4(aw + ct * 64, pbase + rt * prt, h);
+          *reinterpret_cast<float4*>(otile + rt * R48_USERS * LDA + 16 * ct) = h;
+        }
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- out layer: tanh, Y, loss partial sums (:196-198), from registers
+  gchar* yw = uniform_gptr(a.Y + grow0 * a.ldy);
+  const uint32_t ybase = (uint32_t)((myrow * a.ldy + mycol) * 4), yrt = (uint32_t)(R48_USERS * a.ldy * 4);
+  const bool uok = u0 + myrow < a.B;
+  double sD = 0, sC = 0, sR = 0, sR2 = 0;
+#pragma unroll
+  for (int ct = 0; ct < CW; ++ct) {
+    if (!ALLV && CW * wc + ct >= NCT) continue;
+    const int col = mycol + 16 * ct;
+    float fD = 0.f, fC = 0.f, fR = 0.f, fR2 = 0.f;
+    float P[4], S[4], Q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { P[i] = tanh_fast(acc[0][ct][i]); S[i] = tanh_fast(acc[1][ct][i]); Q[i] = tanh_fast(acc[2][ct][i]); }
+    gstore4(yw + ct * 64, ybase, make_float4(P[0], P[1], P[2], P[3]));
+    gstore4(yw + ct * 64, ybase + yrt, make_float4(S[0], S[1], S[2], S[3]));
+    gstore4(yw + ct * 64, ybase + 2 * yrt, make_float4(Q[0], Q[1], Q[2], Q[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (uok && col + i < a.L) {
+        const float R = P[i] - xq[ct][i];
+        const float D = (Q[i] - S[i]) * (1.f / MU2) - R;
+        const float RS = R - S[i];
+        fD += D * D; fC += RS * RS; fR += R; fR2 += R * R;
+      }
+    }
+    sD += fD; sC += fC; sR += fR; sR2 += fR2;
+  }
+  double tot[4] = {sD, sC, sR, sR2};
+  block_sum4(tot, red);
+  if (tid == 0) {
+    double* o = a.loss_part + 4 * (size_t)g;
+    o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3];
+  }
+}
+
+// The whole input-gradient chain of such a step in ONE launch (dgrad_rows.h: k_dgrad_chain, on 48-row work-groups): the loss value
+// and the gradient seeds of the work-group's 16 users, then every layer's dgrad from the output layer down.
+// `pad_rows`: stacked rows behind the last group up to the padded row count the tile kernels may sum over (a weight gradient on the
+// 64-row tiles): the last work-group zero-fills them in dY and every layer's output, whatever an earlier step left there.
+struct DgradChain48Args {
+  DgradChainArgs c;
+  int pad_rows;
+};
+
+template <int CT, bool LIGHT = false>
+__global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradChain48Args ca) {
+  typedef Rows48Cfg<CT> C;
+  constexpr int CW = C::CW, NCT = C::NCT, NQ = C::NQ;
+  __shared__ float red[4];
+  __shared__ double shs[4], tot[4];
+  const DgradChainArgs& c = ca.c;
+  const SeedArgs& a = c.seed;
+  const int tid = threadIdx.x, g = blockIdx.x;
+  {
+    // the five sums: given (sharded step, after the all-reduce) or folded here from the forward's per-work-group partials,
+    // exactly as k_loss_seed does
+    double s0, s1, s2, s3, N;
+    if (a.sums) {
+      s0 = a.sums[0]; s1 = a.sums[1]; s2 = a.sums[2]; s3 = a.sums[3]; N = a.sums[4];
+    } else {
+      double v[4] = {0, 0, 0, 0};
+      for (int i = tid; i < a.nblk; i += NTHREADS)
+        for (int j = 0; j < 4; ++j) v[j] += a.part[4 * (size_t)i + j];
+      for (int j = 0; j < 4; ++j) {
+        const double t = block_sum(v[j], shs);
+        if (tid == 0) tot[j] = t;
+      }
+      __syncthreads();
+      s0 = tot[0]; s1 = tot[1]; s2 = tot[2]; s3 = tot[3]; N = a.count;
+    }
+    const double A = s0 / N, Cc = s1 / N, Rbar = s2 / N;
+    const double V = (N > 1.0) ? (s3 - N * Rbar * Rbar) / (N - 1.0) : __builtin_nan("");
+    const double den = 1e-8 + V;
+    const double k = 0.5 / den;
+    const float cD = (float)(2.0 * k / N);
+    const float cV = (float)(-(0.5 * (A + Cc) / (den * den)) * 2.0 / (N - 1.0));
+    const float rbar = (float)Rbar;
+    if (g == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + Cc) / den);
+    // thread -> (user tid / 16 of the group, column quads tid % 16 + 16 j)
+    const int su = tid >> 4, sq = tid & 15, r = R48_USERS * g + su;
+    const size_t rowP = (size_t)R48_ROWS * g + su;
+    float4 P4[NQ], S4[NQ], Q4[NQ], X4[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int col = 4 * (sq + 16 * j);
+      const size_t yP = rowP * a.LP + col, yS = yP + (size_t)R48_USERS * a.LP, yQ = yS + (size_t)R48_USERS * a.LP;
+      const bool ok = r < a.B && col < a.L;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      P4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yP) : z;
+      S4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yS) : z;
+      Q4[j] = ok ? *reinterpret_cast<const float4*>(a.Y + yQ) : z;
+      X4[j] = ok ? load4_unpadded(a.x0, r, col, a.L) : z;
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int col = 4 * (sq + 16 * j);
+      if (col >= a.LP) continue;
+      const size_t yP = rowP * a.LP + col, yS = yP + (size_t)R48_USERS * a.LP, yQ = yS + (size_t)R48_USERS * a.LP;
+      f32x4 gP = {0.f, 0.f, 0.f, 0.f}, gS = gP, gQ = gP;
+      if (r < a.B && col < a.L) {
+        const f32x4 P = {P4[j].x, P4[j].y, P4[j].z, P4[j].w}, S = {S4[j].x, S4[j].y, S4[j].z, S4[j].w},
+                    Q = {Q4[j].x, Q4[j].y, Q4[j].z, Q4[j].w}, X = {X4[j].x, X4[j].y, X4[j].z, X4[j].w};
+        const f32x4 R = P - X;
+        const f32x4 D = (Q - S) * (1.f / MU2) - R;
+        const f32x4 gD = cD * D;
+        const f32x4 gC = cD * (R - S);
+        const f32x4 gV = cV * (R - rbar);
+        const f32x4 gDm = gD * (1.f / MU2);
+        gP = (-gD + gC + gV) * (1.f - P * P);
+        gQ = gDm * (1.f - Q * Q);
+        gS = (-gDm - gC) * (1.f - S * S);
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+          if (col + i >= a.L) { gP[i] = 0.f; gQ[i] = 0.f; gS[i] = 0.f; }
+      }
+      *reinterpret_cast<float4*>(a.dY + yP) = make_float4(gP[0], gP[1], gP[2], gP[3]);
+      *reinterpret_cast<float4*>(a.dY + yS) = make_float4(gS[0], gS[1], gS[2], gS[3]);
+      *reinterpret_cast<float4*>(a.dY + yQ) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
+    }
+    if (g == (int)gridDim.x - 1 && ca.pad_rows > 0) {
+      // the padding rows behind the last group: zero gradients in every buffer a weight gradient may read them from
+      const size_t r0 = (size_t)R48_ROWS * gridDim.x;
+      const int q4 = a.LP >> 2;
+      for (int i = tid; i < ca.pad_rows * q4; i += NTHREADS)
+        *reinterpret_cast<float4*>(a.dY + (r0 + i / q4) * a.LP + 4 * (i % q4)) = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int l = 0; l < c.nlayers; ++l) {
+        const int ldo = c.layer[l].ldo, qo = ldo >> 2;
+        for (int i = tid; i < ca.pad_rows * qo; i += NTHREADS)
+          *reinterpret_cast<float4*>(c.layer[l].out + (r0 + i / qo) * ldo + 4 * (i % qo)) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  for (int l = 0; l < c.nlayers; ++l) {
+    __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
+    dr_layer<CW, LIGHT, R48_ROWS, NCT>(c.layer[l], g, red);
+  }
+}
+
+}  // namespace sdrm

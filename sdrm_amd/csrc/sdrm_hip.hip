@@ -21,6 +21,7 @@
 #include "gemm.h"
 #include "rank.h"
 #include "rowchain.h"
+#include "rows48.h"
 #include "select.h"
 #include "skinny.h"
 #include "skinny_step.h"
@@ -63,6 +64,9 @@ struct Tuning {
   int dgrad_rows = 1;            // SDRM_DGRAD_ROWS: row-owned input gradients (csrc/dgrad_rows.h) behind the row-owned forward: 0 off,
                                  // 1 the whole chain (loss seeds + every layer) in one launch, 2 k_loss_seed + one launch per layer
   int strips = 1;                // SDRM_WGRAD_STRIPS: strip-owned weight gradients (csrc/wgrad2.h) behind the row-owned forward: 0 off
+  int rows48 = 1;                // SDRM_ROWS48: the row-owned train step on 48-row work-groups (csrc/rows48.h: 16 users' P, S, Q rows; the
+                                 // same nets as rowchain) for batches that do not fill the chip with 96-row work-groups: 0 never, 1 when
+                                 // the batch's 16-user groups fill most of one round of the chip (see use_rows48), 2 whenever the net allows
   int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
                                  // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
 };
@@ -83,6 +87,8 @@ struct sdrm_engine {
                                                           // (layer 0: the latent columns only); null when the net does not qualify
   bool cur_grouped = false;          // stacked row order of the last train_forward (elementwise.h: stacked_row)
   bool cur_sk = false;               // ... grouped by 16 users (the narrow nets' step, csrc/skinny_step.h)
+  bool cur_g16 = false;              // ... grouped by 16 users by the 48-row row-owned forward (csrc/rows48.h)
+  int cur_rows = 0;                  // stacked rows the last train_forward really wrote (whole groups; cur_MP rounds them up to the tile)
   int cur_sk_np = 0;                 // ... and the loss partials its forward left (G, or 4 G: csrc/skinny_fwd4.h)
   bool tables_fresh = false;         // B0tab / the C0^T columns of W0c belong to the current parameters
   float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
@@ -518,7 +524,7 @@ int launch_adam(sdrm_engine* e, const float* grad, float lr, int update, hipStre
 // Taken by the one-call backward when the forward was the row-owned one (the operands are stored as the kernel reads them:
 // activations, a ones column for the bias gradients) and the slices stay within the slab count.
 bool use_strips(const sdrm_engine* e) {
-  return e->cur_grouped && e->cur_act && e->ones_col >= 0 && e->tune.strips > 0 && e->H + 2 <= WG2_MAX_PROBLEMS && e->WP >= 128 && e->WP <= 352;
+  return (e->cur_grouped || e->cur_g16) && e->cur_act && e->ones_col >= 0 && e->tune.strips > 0 && e->H + 2 <= WG2_MAX_PROBLEMS && e->WP >= 128 && e->WP <= 352;
 }
 
 template <int NT>
@@ -553,6 +559,7 @@ int launch_wgrad_strips(sdrm_engine* e, int MP, double flops, hipStream_t st) {
   int S = 256 / units;
   if (S < 1) S = 1;
   if (S > S_MAX) S = S_MAX;
+  MP = e->cur_rows;   // the rows the forward wrote (whole groups, a multiple of 16): the padding behind them is not summed over
   const int kchunk = round_up((MP + S - 1) / S, WG2_BK);
   const int slices = (MP + kchunk - 1) / kchunk;
   for (int k = H; k >= 1; --k)   // the shared hidden layer: one problem per application, slabs [application][slice]
@@ -688,7 +695,68 @@ bool use_rowchain(const sdrm_engine* e, int B) {
   if (e->tune.rowchain >= 2) return true;
   const int G = (B + RC_USERS - 1) / RC_USERS;
   const int rounds = (G + 255) / 256;
-  return G >= 216 && G * 6 >= rounds * 256 * 5;
+  // one round: from 154 groups (B = 4897) on the three row-owned launches beat the per-layer path's eleven although two fifths of
+  // the CUs idle (round 5, tools/rows48_probe.py: B = 5120 383 against 397 us, B = 6144 406 against 462); several rounds: the
+  // last one at least five sixths full
+  return rounds == 1 ? G >= 154 : G * 6 >= rounds * 256 * 5;
+}
+
+// The same step on 48-row work-groups (csrc/rows48.h), for batches the 96-row kernels would leave CUs idle with: the 16-user groups
+// of the batch should fill most of ONE round of the chip (two work-groups fit a CU, but the second round's worth then shares the
+// matrix pipes: no faster than the per-layer path).  Above 256 groups the 96-row kernels or the per-layer path take over.
+bool use_rows48(const sdrm_engine* e, int B) {
+  if (!e->W0f || e->tune.rows48 <= 0 || e->tune.force_cfg >= 0 || e->tune.rowchain >= 2) return false;
+  if (e->tune.rows48 >= 2) return true;
+  const int G = (B + R48_USERS - 1) / R48_USERS;
+  return G >= 176 && G <= 256;
+}
+
+template <int CT>
+int launch_rows48_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStream_t st) {
+  const double flops = 2.0 * 3 * a.B * ((double)e->W * e->L + (double)e->H * e->W * e->W + (double)e->L * e->W);
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_ROW_FWD);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_ROW_FWD);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  if (a.light) SDRM_LAUNCH(e, (k_rows48_fwd<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_rows48_fwd<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  return SDRM_OK;
+}
+
+template <int CT>
+int launch_rows48_chain_ct(sdrm_engine* e, const DgradChain48Args& a, int G, double flops, hipStream_t st) {
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_DGRAD_ROWS);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_DGRAD_ROWS);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  return SDRM_OK;
+}
+
+int launch_rows48_chain(sdrm_engine* e, const DgradChain48Args& a, int G, double flops, hipStream_t st) {
+  switch (e->WP / 32) {
+    case 4: return launch_rows48_chain_ct<4>(e, a, G, flops, st);
+    case 5: return launch_rows48_chain_ct<5>(e, a, G, flops, st);
+    case 6: return launch_rows48_chain_ct<6>(e, a, G, flops, st);
+    case 7: return launch_rows48_chain_ct<7>(e, a, G, flops, st);
+    case 8: return launch_rows48_chain_ct<8>(e, a, G, flops, st);
+    case 9: return launch_rows48_chain_ct<9>(e, a, G, flops, st);
+    case 10: return launch_rows48_chain_ct<10>(e, a, G, flops, st);
+    default: return launch_rows48_chain_ct<11>(e, a, G, flops, st);
+  }
 }
 
 template <int CT>
@@ -711,7 +779,7 @@ int launch_row_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStrea
 }
 
 int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd, uint64_t seed,
-                       uint64_t step, float nd, int G, hipStream_t st) {
+                       uint64_t step, float nd, int G, hipStream_t st, bool rows48 = false) {
   const int n = e->T + 1;
   RowChainArgs a{};
   a.x0 = x0;
@@ -726,6 +794,19 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
   a.act = e->act;
   a.loss_part = e->loss_part;
+  if (rows48) {
+    switch (e->WP / 32) {
+      case 4: return launch_rows48_forward_ct<4>(e, a, G, st);
+      case 5: return launch_rows48_forward_ct<5>(e, a, G, st);
+      case 6: return launch_rows48_forward_ct<6>(e, a, G, st);
+      case 7: return launch_rows48_forward_ct<7>(e, a, G, st);
+      case 8: return launch_rows48_forward_ct<8>(e, a, G, st);
+      case 9: return launch_rows48_forward_ct<9>(e, a, G, st);
+      case 10: return launch_rows48_forward_ct<10>(e, a, G, st);
+      case 11: return launch_rows48_forward_ct<11>(e, a, G, st);
+      default: return fail(e, SDRM_ERR_SHAPE, "row-owned forward: padded width outside 128..352");
+    }
+  }
   switch (e->WP / 32) {
     case 4: return launch_row_forward_ct<4>(e, a, G, st);
     case 5: return launch_row_forward_ct<5>(e, a, G, st);
@@ -942,6 +1023,14 @@ int sdrm_debug_set_rowchain(sdrm_engine* e, int mode) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_rows48(sdrm_engine* e, int mode) {
+  if (!e) return SDRM_ERR_ARG;
+  if (e->bwd_begun) return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_rows48: between sdrm_train_backward_begin and _finish");
+  e->fwd_done = false;   // a pending forward's stacked row order belongs to the old setting
+  e->tune.rows48 = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return SDRM_OK;
+}
+
 int sdrm_debug_rowchain_available(const sdrm_engine* e) { return e && e->W0f ? 1 : 0; }
 
 int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
@@ -1063,6 +1152,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_AR_BUCKETS")) e->tune.ar_buckets = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_ROWS48")) e->tune.rows48 = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
   if (const char* env = std::getenv("SDRM_DGRAD_ROWS")) e->tune.dgrad_rows = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
@@ -1267,7 +1357,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
 
-  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false;
+  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false; e->cur_g16 = false; e->cur_rows = MP;
   if (skinny_net(e)) {
     // narrow net (csrc/skinny_step.h): staging, all layers and the loss partial sums of 16 users' P, S, Q rows per work-group in
     // ONE launch; the tables B0tab = b0 + C0[t] come from the last step's tail (or are made now, after a parameter upload)
@@ -1295,7 +1385,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
                          sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
-    e->cur_B = B; e->cur_MP = round_up(SK_ROWS * ka.G, BM); e->cur_x0 = x0; e->cur_sk = true; e->fwd_done = true;
+    e->cur_B = B; e->cur_MP = round_up(SK_ROWS * ka.G, BM); e->cur_rows = SK_ROWS * ka.G; e->cur_x0 = x0; e->cur_sk = true; e->fwd_done = true;
     return SDRM_OK;
   }
 
@@ -1312,7 +1402,23 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
                          sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
-    e->cur_B = B; e->cur_MP = MPg; e->cur_x0 = x0; e->cur_grouped = true; e->cur_act = true; e->fwd_done = true;
+    e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * RC_ROWS; e->cur_x0 = x0; e->cur_grouped = true; e->cur_act = true; e->fwd_done = true;
+    return SDRM_OK;
+  }
+
+  if (use_rows48(e, B)) {
+    // the same on 48-row work-groups (rows48.h): tables, then ONE launch
+    int rc = emb_tables(e, st, x0, (size_t)B * e->L);
+    if (rc) return rc;
+    const int G = (B + R48_USERS - 1) / R48_USERS, MPg = round_up(G * R48_ROWS, BM);
+    rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st, true);
+    if (rc) return rc;
+    if (!e->fold_sums) {
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, G, (double)B * (double)e->L,
+                         sums ? sums : e->sums);
+      HIP_TRY(e, hipGetLastError());
+    }
+    e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * R48_ROWS; e->cur_x0 = x0; e->cur_g16 = true; e->cur_act = true; e->fwd_done = true;
     return SDRM_OK;
   }
 
@@ -1383,12 +1489,15 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   e->bwd_strips = false;
   SeedArgs sa{};
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
-  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0);
-  sa.part = e->loss_part; sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : LOSS_BLOCKS; sa.count = (double)B * (double)e->L;
+  sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0);
+  sa.part = e->loss_part;
+  sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : (e->cur_g16 ? (B + R48_USERS - 1) / R48_USERS : LOSS_BLOCKS);
+  sa.count = (double)B * (double)e->L;
   // the row-owned chain (dgrad_rows.h) computes the seeds itself; every other path launches k_loss_seed
-  const bool chain = use_dgrad_rows(e, MP) && e->tune.dgrad_rows == 1 && H + 1 <= DR_MAX_LAYERS;
+  const bool chain48 = e->cur_g16 && e->WhfT && e->tune.dgrad_rows > 0 && e->LP == e->WP && H + 1 <= DR_MAX_LAYERS;
+  const bool chain = chain48 || (use_dgrad_rows(e, MP) && e->tune.dgrad_rows == 1 && H + 1 <= DR_MAX_LAYERS);
   if (!chain && !e->cur_sk) {
-    const int nslots = e->cur_grouped ? RC_USERS * ((B + RC_USERS - 1) / RC_USERS) : B;
+    const int nslots = e->cur_grouped ? RC_USERS * ((B + RC_USERS - 1) / RC_USERS) : (e->cur_g16 ? R48_USERS * ((B + R48_USERS - 1) / R48_USERS) : B);
     const unsigned need = (unsigned)(((size_t)(nslots + (MP - 3 * nslots)) * (e->LP / 4) + 255) / 256);
     dim3 grid(std::min(need, 2048u));   // grid-stride beyond: see k_loss_seed
     SDRM_LAUNCH(e, k_loss_seed, grid, dim3(256), 0, st, sa);
@@ -1418,6 +1527,27 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
     if (rc) return rc;
     e->bwd_S0 = e->bwd_SH = e->bwd_SO = S; e->bwd_hidden_apps = 1; e->bwd_dgrad_blocks = S;
     e->bwd_kc0 = e->bwd_kcH = e->bwd_kcO = 0;
+    return SDRM_OK;
+  }
+  if (chain48) {
+    // one work-group per 48 stacked rows runs the whole chain (csrc/rows48.h): one slope partial per work-group and layer
+    DgradChain48Args c8{};
+    DgradChainArgs& ca = c8.c;
+    ca.seed = sa; ca.nlayers = H + 1;
+    ca.layer[0] = dgrad_rows_args(e, e->dY, e->WofT, pre_buf(e, H), slope_ptr(e, H), dpre_buf(e, H), e->alpha_part + (size_t)H * e->alpha_part_stride);
+    for (int k = H; k >= 1; --k)
+      ca.layer[H + 1 - k] = dgrad_rows_args(e, dpre_buf(e, k), e->WhfT, pre_buf(e, k - 1), slope_ptr(e, k - 1), dpre_buf(e, k - 1),
+                                            e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride);
+    const int Gn = e->cur_rows / R48_ROWS;
+    c8.pad_rows = MP - e->cur_rows;
+    int rc = launch_rows48_chain(e, c8, Gn, flO + H * flH, st);
+    if (rc) return rc;
+    if (with_wgrad0)
+      HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
+                                      Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
+    e->bwd_kc0 = kc0;
+    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = Gn;
+    e->bwd_kcH = kcH; e->bwd_kcO = kcO;
     return SDRM_OK;
   }
   if (use_dgrad_rows(e, MP)) {
@@ -1826,7 +1956,7 @@ int sdrm_get_train_outputs(const sdrm_engine* e, float* psq, void* stream) {
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_train_outputs: no forward yet");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)e->Y, e->cur_B, e->L,
-                     e->LP, e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0), psq);
+                     e->LP, (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0), psq);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }
@@ -2150,7 +2280,7 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
   if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
   SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
-                     e->cur_B, e->W, e->WP, e->cur_sk ? 2 : (e->cur_grouped ? 1 : 0), out);
+                     e->cur_B, e->W, e->WP, (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0), out);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }

@@ -103,13 +103,15 @@ class Engine:
         return t.contiguous()
 
     def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None,
-                  gradient_buckets=None, rowchain=None, wgrad_strips=None, dgrad_rows=None):
+                  gradient_buckets=None, rowchain=None, wgrad_strips=None, dgrad_rows=None, rows48=None):
         """Test / tuning hooks of THIS engine (include/sdrm_hip_debug.h): force a GEMM tile shape (-1 = automatic),
         switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds,
         the number of gradient all-reduces of the sharded step (1 or 2), the row-owned train forward (0 never, 1 by
         size, 2 whenever the net allows), the strip-owned weight gradients and the row-owned input gradients behind it."""
         if rowchain is not None:
             self._check(self.lib.sdrm_debug_set_rowchain(self._h, int(rowchain)), "sdrm_debug_set_rowchain")
+        if rows48 is not None:   # the same step on 48-row work-groups (csrc/rows48.h): 0 never, 1 by size, 2 whenever the net allows
+            self._check(self.lib.sdrm_debug_set_rows48(self._h, int(rows48)), "sdrm_debug_set_rows48")
         if wgrad_strips is not None:
             self._check(self.lib.sdrm_debug_set_wgrad_strips(self._h, int(bool(wgrad_strips))), "sdrm_debug_set_wgrad_strips")
         if dgrad_rows is not None:

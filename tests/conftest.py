@@ -40,6 +40,14 @@ def engine_cls():
 
     class TestEngine(Engine):
         def debug_set(self, **kw):
+            if kw.get("tile") in ("row48", "row48-tiles"):
+                # the row-owned step on 48-row work-groups (csrc/rows48.h) forced on: "row48" with its dgrad chain and the strip-owned
+                # weight gradients behind it, "row48-tiles" the same forward with k_loss_seed + tile dgrads + batched tile weight gradients
+                if not self.rowchain_available:
+                    self.close()
+                    pytest.skip("shape outside the row-owned forward's envelope")
+                mode = kw["tile"]
+                kw = dict(kw, tile=None, rowchain=0, rows48=2, wgrad_strips=mode == "row48", dgrad_rows=1 if mode == "row48" else 0)
             if kw.get("tile") in ("row", "row-layers", "row-tiles"):
                 if not self.rowchain_available:
                     self.close()

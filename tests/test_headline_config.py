@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 L, W, T, H = 340, 340, 78, 1
 B_TRAIN, N_SAMPLE = 8192, 5429
 TILES = [-1, 0, 4]          # automatic, 64x64x16 on the 32-wide MFMA, 32x32x32 on the 16-wide MFMA
-TRAIN_PATHS = TILES + ["row", "row-layers", "row-tiles"]   # ... and the row-owned forward forced on (what the automatic choice takes at this batch, whatever
+TRAIN_PATHS = TILES + ["row", "row-layers", "row-tiles", "row48"]   # ... and the row-owned forward forced on (what the automatic choice takes at this batch, whatever
                                 # its size rule becomes)
 ND = 0.9
 

@@ -41,7 +41,9 @@ def sampler_path(request):
 
 TILES = [-1, 0, 4]   # automatic; forced 64x64x16 (32-wide MFMA); forced 32x32x32 (16-wide MFMA): every step-level test
                      # below runs on each, so a size-threshold retune cannot change which kernels the suite covers
-TRAIN_PATHS = TILES + ["row", "row-layers", "row-tiles"]   # train-step tests also run through the row-owned forward (csrc/rowchain.h, grouped row order)
+ROW_PATHS = ["row", "row-layers", "row-tiles", "row48", "row48-tiles"]   # the row-owned forwards: 96-row work-groups (csrc/rowchain.h) with each
+                     # backward behind them, 48-row work-groups (csrc/rows48.h) with their own chain + strips, or with the tile backward
+TRAIN_PATHS = TILES + ROW_PATHS   # train-step tests also run through the row-owned forwards (grouped row orders)
 
 
 @pytest.fixture(params=TILES, ids=lambda t: f"tile{t}")
@@ -165,7 +167,7 @@ def test_train_golden(engine_cls, golden, train_path, fixture):
     gradient tensor (shared hidden layer accumulation, Q1), post-Adam parameters across the
     epoch boundary, final Adam moments.  `train_wide` holds a net inside the row-owned forward's envelope."""
     tile = train_path
-    if tile in ("row", "row-layers", "row-tiles") and fixture != "train_wide":
+    if tile in ROW_PATHS and fixture != "train_wide":
         pytest.skip("no case of this fixture lies inside the row-owned forward's envelope")
     g = golden(fixture)
     for ci in range(int(g["n_cases"])):
@@ -274,7 +276,7 @@ def engine_branch_masks(e, o, caches, B, kink_tol=2e-5):
 
 
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (40, 40, 93, 5, 850), (830, 830, 83, 2, 550),
-                                  (50, 70, 5, 0, 33), (100, 100, 198, 3, 129), (340, 340, 78, 1, 2048),
+                                  (50, 70, 5, 0, 33), (100, 100, 198, 3, 129), (340, 340, 78, 1, 2048), (340, 340, 78, 1, 4096),
                                   (96, 96, 5, 1, 45000)])   # 135 000 stacked rows: > 4096 slope partials per application
 def test_train_step_vs_oracle(engine_cls, dims, train_path):
     """Full tensors (not checksums) against the CPU oracle at sizes it finishes in seconds.  The oracle
@@ -377,7 +379,7 @@ def test_narrow_net_steps_are_reproducible(engine_cls, dims):
     assert rel_l2(a, d) <= TOL and np.allclose(la, ld, rtol=1e-4)
 
 
-@pytest.mark.parametrize("path", [-1, "row", "row-layers", "row-tiles"])
+@pytest.mark.parametrize("path", [-1] + ROW_PATHS)
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (41, 40, 93, 5, 50), (24, 24, 9, 2, 7), (130, 130, 12, 2, 77)])
 def test_philox_mode_train(engine_cls, dims, path):
     """PHILOX mode == EXPLICIT mode fed with the numpy restatement of the device generator: integer
@@ -472,7 +474,8 @@ def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
         return loss, g, p
 
     ref = grads(-1)
-    for path, two_call in (("row", False), ("row-layers", False), ("row-tiles", False), ("row", True)):
+    for path, two_call in (("row", False), ("row-layers", False), ("row-tiles", False), ("row", True), ("row48", False), ("row48-tiles", False),
+                           ("row48", True)):
         loss, g, p = grads(path, two_call)
         assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0])
         for (n, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(ref[1], (L, W, T, H))):

@@ -33,7 +33,7 @@ def _compile(instantiations: str) -> str:
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "k.hip")
         with open(src, "w") as f:
-            f.write(f'#include "{CSRC}/dgrad_rows.h"\n' + instantiations)
+            f.write(f'#include "{CSRC}/rows48.h"\n' + instantiations)
         out = os.path.join(d, "k.s")
         res = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
                              capture_output=True, text=True)
@@ -85,27 +85,31 @@ def test_row_owned_kernels_isa(ct):
     light = "true" if ct == 11 else "false"   # the compact last K-step (340 = 21 * 16 + 4) on the headline width, plain on the other
     asm = _compile(f"template __global__ void sdrm::k_dgrad_chain<{ct}, {light}>(const sdrm::DgradChainArgs);\n"
                    f"template __global__ void sdrm::k_dgrad_rows<{ct}, {light}>(const sdrm::DgradRowsArgs);\n"
-                   f"template __global__ void sdrm::k_row_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n")
+                   f"template __global__ void sdrm::k_row_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n"
+                   # the same step on 48-row work-groups (csrc/rows48.h): the same asm MFMAs through the same K-step templates
+                   f"template __global__ void sdrm::k_rows48_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n"
+                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}>(const sdrm::DgradChain48Args);\n")
     ks = _kernels(asm)
-    names = {"chain": [n for n in ks if "k_dgrad_chain" in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
-             "fwd": [n for n in ks if "k_row_fwd" in n]}
+    names = {"chain": [n for n in ks if "k_dgrad_chain" in n and "rows48" not in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
+             "fwd": [n for n in ks if "k_row_fwd" in n], "fwd48": [n for n in ks if "k_rows48_fwd" in n],
+             "chain48": [n for n in ks if "k_rows48_dgrad_chain" in n]}
     assert all(len(v) == 1 for v in names.values()), names
     for kind, (name,) in names.items():
         ins = ks[name]
         mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
-        assert len(mf) >= 100, (kind, len(mf))
+        assert len(mf) >= (100 if "48" not in kind else 48), (kind, len(mf))
         # K loops: the loops that hold MFMAs
         loops = _loops(ins)
         inner = [(a, b) for a, b in loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in loops)]
         # (the layer loops have barriers, a K loop has none)
         kloops = [(a, b) for a, b in inner if sum(1 for x in ins[a:b] if x.startswith("v_mfma")) >= 24 and "s_barrier" not in ins[a:b]]
         # (a K loop of a single trip is straight-line code: the narrowest nets of the dgrad kernels)
-        assert kloops or (kind != "fwd" and ct <= 5), kind
+        assert kloops or (not kind.startswith("fwd") and ct <= 5), kind
         for a, b in kloops:
             body = ins[a:b]
             assert not [x for x in body if x.startswith("v_accvgpr")], (kind, "accumulator copies inside a K loop")
             assert not [x for x in body if x.startswith("scratch_")], (kind, "scratch access inside a K loop")
-            if kind != "fwd":
+            if not kind.startswith("fwd"):
                 valu = [x for x in body if x.startswith("v_") and not x.startswith(VALU_OK_IN_LOOP)]
                 assert not valu, (kind, "VALU inside a K loop", valu[:4])
             else:

@@ -17,7 +17,8 @@ CONFIGS = {"ml100k": dict(L=830, W=830, T=83, H=2, B=550, n=843), "ml1m_b160": d
            "adm": dict(L=40, W=40, T=93, H=5, B=850, n=9558), "ml1m": dict(L=340, W=340, T=78, H=1, B=8192, n=5429),
            "ml1m_shard8": dict(L=340, W=340, T=78, H=1, B=1024, n=679), "ml1m_b512": dict(L=340, W=340, T=78, H=1, B=512, n=5429),
            "ml1m_b2048": dict(L=340, W=340, T=78, H=1, B=2048, n=5429),
-           "ml1m_n5120": dict(L=340, W=340, T=78, H=1, B=8192, n=5120)}
+           "ml1m_n5120": dict(L=340, W=340, T=78, H=1, B=8192, n=5120),
+           "ml1m_shard2": dict(L=340, W=340, T=78, H=1, B=4096, n=2715), "ml1m_shard4": dict(L=340, W=340, T=78, H=1, B=2048, n=1358)}
 c = CONFIGS[sys.argv[1]]
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 e = Engine(c["L"], c["W"], c["T"], c["H"], max_rows=max(c["B"], c["n"]))
