@@ -52,6 +52,19 @@ int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
  * and a forced tile take precedence.  The stacked rows of such a step are grouped by 16 users (elementwise.h).  Refused between
  * sdrm_train_backward_begin and _finish; drops a pending train forward. */
 int sdrm_debug_set_rows48(sdrm_engine* e, int mode);
+/* Column-split row groups of that step (csrc/rows48.h): G work-groups of ONE XCD share a 48-row group - each owns 1 / G of every
+ * layer's output columns and pulls the rest of the next layer's input through that XCD's L2 (work-group-scope atomics + sc1 loads,
+ * no device-scope fence) - so that batches of at most 2048 users fill the chip in 6 launches instead of 11: 0 never, 1 (default) by
+ * size (1281..2048 users: 2 work-groups per group), 2 / 4 that many whenever groups x G fit the 256 CUs (every
+ * work-group of such a launch must be resident at once); also env SDRM_ROWS48_SPLIT.  Needs the chip's block -> XCD mapping
+ * (checked by sdrm_create: sdrm_debug_rows48_split_available).  A hand-shake that times out (30 ms) is reported by the next train
+ * call on the handle as SDRM_ERR_HIP and switches the path off for the handle. */
+int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode);
+int sdrm_debug_rows48_split_available(const sdrm_engine* e);
+/* Fault injection for that path: the NEXT column-split launch waits for a count its group never reaches (its base is moved up by
+ * `skew`), so every work-group of it runs into the 30 ms bound of its first hand-shake, raises the abort word and returns; the
+ * next train call on the handle then reports SDRM_ERR_HIP and the handle continues on the per-layer path. */
+int sdrm_debug_split_skew(sdrm_engine* e, unsigned skew);
 /* Strip-owned weight gradients (csrc/wgrad2.h: every weight gradient of a step in one balanced round of one work-group per CU,
  * bias gradients from the ones column of the layer inputs) behind the row-owned forward: 1 (default) on, 0 the batched 64x64-tile
  * split-K launch; also env SDRM_WGRAD_STRIPS.  Takes effect with the next backward. */

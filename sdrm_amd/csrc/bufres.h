@@ -23,6 +23,17 @@ __device__ __forceinline__ f32x4_b bload4(brsrc r, uint32_t voff, uint32_t soff)
 __device__ __forceinline__ float bload1(brsrc r, uint32_t voff, uint32_t soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// ... with cache-policy bits: AUX = 16 is sc1 - the load is served by the XCD's L2, never by this CU's L1 (what a work-group reads
+// of another work-group's stores of the SAME launch, csrc/rows48.h)
+constexpr int BUF_SC1 = 16;
+template <int AUX>
+__device__ __forceinline__ f32x4_b bload4a(brsrc r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4_b, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ float bload1a(brsrc r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, AUX));
+}
 // NT: the non-temporal hint - bytes nobody reads before the weight gradients, a whole backward chain later (U, the activations):
 // they should not push the pre-activations and Y, which the loss seeds and the dgrads read next, out of the caches
 template <bool NT>

@@ -52,7 +52,8 @@ struct DgradRowsArgs {
 // opaque scalar base (see rc_kstep).
 // MODE (rowchain.h): RC_NEXT_LIGHT - the G pieces fetch the compact fragments of the layer's last K-step (one float per lane at
 // k = 16 ks + lane group: `goff` then holds those offsets); RC_LIGHT - this is that K-step: one MFMA per tile.
-template <int CT, int PH, int NA, int NB, int PRE0, int NPRE, int MODE = RC_PLAIN>
+// GAUX: cache policy of the G fragment loads (bufres.h; BUF_SC1 where another work-group of the launch wrote G)
+template <int CT, int PH, int NA, int NB, int PRE0, int NPRE, int MODE = RC_PLAIN, int GAUX = 0>
 __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc gr, uint32_t gnext,
                                          const uint32_t (&goff)[3], brsrc wr_, uint32_t wnext, uint32_t lane16, f32x4 (&pq)[3 * CT],
                                          brsrc pr, const uint32_t (&poff)[3]) {
@@ -91,8 +92,8 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
         if (!(DR_DIAG & 2)) {
           uint32_t so = gnext;
           asm volatile("" : "+s"(so));
-          if (MODE == RC_NEXT_LIGHT) al[p - NB][0] = bload1(gr, goff[p - NB], so);
-          else al[p - NB] = bload4(gr, goff[p - NB], so);
+          if (MODE == RC_NEXT_LIGHT) al[p - NB][0] = bload1a<GAUX>(gr, goff[p - NB], so);
+          else al[p - NB] = bload4a<GAUX>(gr, goff[p - NB], so);
         }
       } else {
         const int q = PRE0 + (p - NB - NA), rt2 = q / CT, ct2 = q % CT;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
 // still to come, and takes its share of the 3 * CT pre-activation quads - spread over all of them: in the last two K-steps alone
 // they are a 35 MB burst chip-wide, more than HBM delivers in that time
 // LIGHT: K-step KS - 1 is the compact one (its G fragments, fetched by K-step KS - 3, come from `goffl`)
-template <int CT, int KS, int PEEL, bool LIGHT, int J, int NCT = 2 * CT>
+template <int CT, int KS, int PEEL, bool LIGHT, int J, int NCT = 2 * CT, int GAUX = 0>
 __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc Gw, const uint32_t (&goff)[3],
                                         const uint32_t (&goffl)[3], brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw,
                                         const uint32_t (&poff)[3]) {
@@ -120,22 +121,24 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
     constexpr int NA = K + 2 < KS ? 3 : 0, NB = K + 1 < KS ? CT : 0;
     constexpr int PRE0 = J * NQ / PEEL, NPRE = (J + 1) * NQ / PEEL - PRE0;
     constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;
-    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf,
-                                                  (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
-    dr_peel<CT, KS, PEEL, LIGHT, J + 1, NCT>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE, GAUX>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf,
+                                                        (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
+    dr_peel<CT, KS, PEEL, LIGHT, J + 1, NCT, GAUX>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   }
 }
 
 // one layer for the work-group's ROWS stacked rows (block index g); `red`: four floats of LDS.
 // ROWS = 96 (this file's kernels: 32 users, waves as 2 x 2, CT column tiles each) or 48 (rows48.h: 16 users, the four waves side
 // by side, CT = ceil(NCT / 4) column tiles each - the last wave's tiles beyond the NCT real ones are computed and dropped).
-template <int CT, bool LIGHT, int ROWS = RC_ROWS, int NCT = 2 * CT>
-__device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red) {
+// SPLIT (rows48.h, several work-groups per row group): this work-group owns the column tiles [t0, t1) only and writes slope partial
+// `pidx`; GAUX: cache policy of its G loads (the other work-groups of the group wrote most of G in this launch).
+template <int CT, bool LIGHT, int ROWS = RC_ROWS, int NCT = 2 * CT, bool SPLIT = false, int GAUX = 0>
+__device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red, int t0 = 0, int t1 = NCT, int pidx = -1) {
   constexpr int KS = NCT, NQ = 3 * CT;
   constexpr int WC = 4 / (ROWS / 48);             // waves side by side along the columns
-  constexpr bool ALLV = CT * WC == NCT;           // every tile of every wave is a real one
+  constexpr bool ALLV = !SPLIT && CT * WC == NCT; // every tile of every wave is a real one
   static_assert(ROWS == 48 || ROWS == 96, "a work-group owns the P, S, Q rows of 16 or 32 users");
-  static_assert(CT * WC >= NCT && (CT - 1) * WC < NCT, "per-wave column tiles do not cover the layer");
+  static_assert(SPLIT || (CT * WC >= NCT && (CT - 1) * WC < NCT), "per-wave column tiles do not cover the layer");
   static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,11 +159,11 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
     const int row = 48 * wr + 16 * rt + li;
     goff[rt] = (uint32_t)((row * a.ldg + 4 * lq) * 4);
     goffl[rt] = (uint32_t)((row * a.ldg + lq) * 4);   // the compact K-step: k = 16 ks + lq
-    poff[rt] = (uint32_t)((row * a.ldp + 16 * CT * wc + 4 * lq) * 4);
-    ooff[rt] = (uint32_t)((row * a.ldo + 16 * CT * wc + 4 * lq) * 4);
+    poff[rt] = (uint32_t)((row * a.ldp + 16 * (t0 + CT * wc) + 4 * lq) * 4);
+    ooff[rt] = (uint32_t)((row * a.ldo + 16 * (t0 + CT * wc) + 4 * lq) * 4);
   }
   const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(ROWS * a.ldg * 4));
-  const brsrc Wf = make_brsrc(a.WfT + (size_t)(CT * wc) * 256, (uint32_t)((KS * NCT - CT * wc) * 1024));
+  const brsrc Wf = make_brsrc(a.WfT + (size_t)(t0 + CT * wc) * 256, (uint32_t)((KS * NCT - (t0 + CT * wc)) * 1024));
   const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
   gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
   const float slope = *a.slope;
@@ -176,8 +179,8 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   // prologue: G fragments of K-steps 0 and 1, W fragments of K-step 0
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
-    A[0][rt] = bload4(Gw, goff[rt], 0u);
-    A[1][rt] = bload4(Gw, goff[rt], 64u);
+    A[0][rt] = bload4a<GAUX>(Gw, goff[rt], 0u);
+    A[1][rt] = bload4a<GAUX>(Gw, goff[rt], 64u);
   }
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) B[0][ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
@@ -190,13 +193,13 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   constexpr int PEEL = KS % 4 == 2 ? (KS >= 14 ? 10 : (KS >= 10 ? 6 : 2)) : (KS >= 12 ? 8 : 4);
   static_assert((KS - PEEL) % 4 == 0 && KS - PEEL >= 4, "the main loop takes whole trips of four K-steps");
   for (uint32_t ks = 0; ks < (uint32_t)(KS - PEEL); ks += 4) {
-    dr_kstep<CT, 0, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 2), goff, Wf, (ks + 1) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 1, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 3), goff, Wf, (ks + 2) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 2, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 4), goff, Wf, (ks + 3) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 3, 3, CT, 0, 0>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 0, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 2), goff, Wf, (ks + 1) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 1, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 3), goff, Wf, (ks + 2) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 2, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 4), goff, Wf, (ks + 3) * WSTEP, lane16, pq, Pw, poff);
+    dr_kstep<CT, 3, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
   }
   DR_STAMP(2);
-  dr_peel<CT, KS, PEEL, LIGHT, 0, NCT>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+  dr_peel<CT, KS, PEEL, LIGHT, 0, NCT, GAUX>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   DR_STAMP(3);
   rc_acc_settle<CT>(acc);
   // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
@@ -205,7 +208,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      if (!ALLV && CT * wc + ct >= NCT) continue;   // (wave-uniform) a tile beyond the layer's columns: what it computed is dropped
+      if (!ALLV && t0 + CT * wc + ct >= t1) continue;   // (wave-uniform) a tile beyond the layer's / the work-group's columns: what it computed is dropped
       const f32x4 p = pq[rt * CT + ct];
       f32x4 v = acc[rt][ct];
       asm("" : "+v"(v));   // one copy out of the accumulator registers, every use below reads it
@@ -223,7 +226,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if (lane == 0) red[wave] = part;
   __syncthreads();
-  if (tid == 0) a.slope_part[g] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid == 0) a.slope_part[pidx >= 0 ? pidx : g] = (red[0] + red[1]) + (red[2] + red[3]);
 #ifdef DR_STAMPS
   DR_STAMP(4);
   if (tid == 0 && a.stamps) {

@@ -404,7 +404,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         for (int h = 0; h < RQ; ++h) {
           float n[4] = {0.f, 0.f, 0.f, 0.f};
           uint32_t bits = 0u;
+#ifndef SDRM_DIAG_REV_NODRAW   // diagnostic builds only (timing the fused epilogue without its Philox work: results are wrong)
           if (p.rev_step > 1) {
+#else
+          if (p.rev_step > 1000000) {
+#endif
             const int slot = p.rev_s0 + rbase + (MF == 32 ? 8 * kq + h : kq);   // rowoff(kq * RQ + h)
             const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 2),
                                        PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);

@@ -71,6 +71,8 @@ struct RowChainArgs {
   float* Y; int ldy;
   double* loss_part;                        // [gridDim.x][4]
   unsigned long long* stamps;               // diagnostic builds only (-DRC_STAMPS): 16 s_memtime slots per work-group
+  // column-split row groups only (rows48.h): the groups' hand-shake counters, and the number of row groups
+  unsigned* xcnt; unsigned xbase; unsigned* xabort; int ngroups;
 };
 
 #ifdef RC_STAMPS

@@ -19,6 +19,21 @@
 //     the narrow nets' kernels use.
 // K-steps, pipeline pieces, asm MFMAs with tied accumulators, swapped operands (a lane holds four consecutive COLUMNS of a row),
 // fragment-packed weights with the compact last K-step: rowchain.h's, through the same rc_kstep / dr_kstep.
+//
+// COLUMN-SPLIT row groups (G = 2 or 4 work-groups per 48-row group; round 5): below 4096 users even 48-row work-groups leave CUs
+// idle - a batch of 1024 users (the 8-GPU shard of the 8192 batch) is 64 groups - and the per-layer path pays eleven launches of
+// 6 - 15 us for 40 us of matrix work.  Here G work-groups share a row group: each stages the whole input tile (the randoms are
+// counter-based: every one draws the same), owns 1 / G of every layer's output columns (its four waves side by side inside that
+// range), stores its columns of the pre-activations and activations, and then PULLS the other work-groups' columns of the
+// activations - which the weight gradients want in HBM anyway - into its LDS tile for the next layer.  What makes that cheap is the
+// chip's topology: work-group b runs on XCD b & 7 (stamps, profiles/r02_wgrad_one_round_and_strips.txt; checked by sdrm_create with
+// a probe launch), so the G work-groups of a group are given block indices on ONE XCD, whose L2 is coherent for its own CUs:
+// stores are acknowledged by that L2 (s_waitcnt vmcnt(0)), a counter per group is bumped by a work-group-scope atomic (executed in
+// that L2) and polled with sc1 loads, the columns are pulled with sc1 loads (served by the L2, never by the CU's L1) - 1.05 us per
+// hand-shake and ~15 B per cycle and CU measured (tools/xcd_local_probe.hip, profiles/r04_xcd_local_probe.txt) against ~4.5 us for
+// a kernel boundary.  No device-scope fence, no L2 write-back.  Every work-group of the launch is resident at once (grids of at most
+// 256 work-groups, one per CU), every wait is bounded by the wall clock (s_memrealtime) and a timeout raises a flag in host-visible
+// memory that the next call on the handle reports (sdrm_hip.hip: split_status).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,45 +46,112 @@ namespace sdrm {
 constexpr int R48_USERS = 16;
 constexpr int R48_ROWS = 3 * R48_USERS;
 
-template <int CT>
+template <int CT, int G = 1>
 struct Rows48Cfg {
-  static constexpr int NP = 32 * CT, NCT = 2 * CT, CW = (NCT + 3) / 4, KS = NP / 16, QP = NP / 4, LDA = rc_lda(NP);
-  static constexpr int NQ = (QP + 15) / 16;   // column quads per staging thread (16 quad lanes per user)
+  static constexpr int NP = 32 * CT, NCT = 2 * CT, KS = NP / 16, QP = NP / 4, LDA = rc_lda(NP);
+  static constexpr int NCG = (NCT + G - 1) / G;    // column tiles of one work-group of a group
+  static constexpr int CW = (NCG + 3) / 4;         // ... of one of its waves
+  static constexpr int NQ = (QP + 15) / 16;        // column quads per staging thread (16 quad lanes per user)
+  static constexpr int NPULL = (R48_ROWS * QP + NTHREADS - 1) / NTHREADS;   // quads of the tile per thread in a sweep over it
   static constexpr size_t LDS_BYTES = (size_t)R48_ROWS * LDA * 4 + 512;
+  static_assert(G == 1 || G == 2 || G == 4, "work-groups per row group");
   static_assert(2 * LDS_BYTES <= 160 * 1024, "two work-groups share a CU's LDS");
 };
 
+// The hand-shake of a column-split row group (see the head of this file).  cnt: the group's counter (one per 128-byte line), never
+// reset: launch number `epoch` counts from base = epoch * phases * G.
+struct SplitSync {
+  unsigned* cnt;        // [groups][32]
+  unsigned base;        // first target of this launch minus G
+  unsigned* abort_;     // host-visible word: != 0 once any wait of any launch timed out
+};
+
+constexpr unsigned long long R48_SPIN_LIMIT = 3000000ull;   // s_memrealtime ticks (100 MHz): 30 ms
+
+__device__ __forceinline__ unsigned r48_poll_l2(const unsigned* p) {   // the counter as the XCD's L2 holds it
+  unsigned v;
+  asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+// every thread's stores of this phase are acknowledged by the L2, then the work-groups of the group meet; false: timed out
+__device__ __forceinline__ bool r48_group_barrier(unsigned* my, unsigned target, unsigned* abort_, int* go) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(my, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int ok = 0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (unsigned spin = 0;; ++spin) {
+      if ((int)(r48_poll_l2(my) - target) >= 0) { ok = 1; break; }
+      if ((spin & 63u) == 63u) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > R48_SPIN_LIMIT) break;
+        if (__hip_atomic_load(abort_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
+      }
+    }
+    if (!ok) __hip_atomic_store(abort_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    *go = ok;
+  }
+  __syncthreads();
+  return *go != 0;
+}
+
+// where work-group b of a launch runs: HW_REG_XCC_ID (id 20) per block; sdrm_create checks "block b on XCD b & 7" with it before the
+// column-split path may be taken
+__global__ void k_xcc_probe(unsigned* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+}
+
+__device__ __forceinline__ f32x4 r48_load_l2(const float* p) {   // 16 bytes as the XCD's L2 holds them (issued, not waited for)
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 // LIGHT: the weight copies' last K-step is compact (a.light; the host picks the instantiation).  Arguments: rowchain.h's.
-template <int CT, bool LIGHT = false>
+// G: work-groups per row group (see the head of this file); grid: G = 1 one work-group per group; G > 1: 8 * G * ceil(groups / 8)
+// work-groups, block b = XCD x = b & 7, slot b >> 3 = (group x + 8 * (slot / G), part slot % G).
+template <int CT, bool LIGHT = false, int G = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a) {
-  typedef Rows48Cfg<CT> C;
-  constexpr int NP = C::NP, NCT = C::NCT, CW = C::CW, KS = C::KS, QP = C::QP, LDA = C::LDA, NQ = C::NQ, RT = 3;
-  constexpr bool ALLV = 4 * CW == NCT;
+  typedef Rows48Cfg<CT, G> C;
+  constexpr int NP = C::NP, NCT = C::NCT, NCG = C::NCG, CW = C::CW, KS = C::KS, QP = C::QP, LDA = C::LDA, NQ = C::NQ, RT = 3;
+  constexpr bool ALLV = 4 * CW == NCG && NCG * G == NCT;   // every tile of every wave is a real one
   static_assert(KS % 2 == 0, "K-steps are taken in pairs");
   __shared__ __attribute__((aligned(16))) float Act[R48_ROWS * LDA];
   __shared__ int trow[R48_USERS];
   __shared__ double red[16];
+  __shared__ int go;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave = its column block
+  const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave = its column block inside the work-group's range
   const int li = lane & 15, lq = lane >> 4;
-  const int g = blockIdx.x, u0 = R48_USERS * g;
-  const size_t grow0 = (size_t)R48_ROWS * g;   // first stacked row of this work-group
+  int g = blockIdx.x, part = 0;
+  if constexpr (G > 1) {
+    const int slot = (int)blockIdx.x >> 3;
+    part = slot % G;
+    g = ((int)blockIdx.x & 7) + 8 * (slot / G);
+    if (g >= a.ngroups) return;   // (the whole group: its work-groups share g)
+  }
+  const int u0 = R48_USERS * g;
+  const size_t grow0 = (size_t)R48_ROWS * g;   // first stacked row of this work-group's group
+  const int t0 = part * NCG, t1 = min(t0 + NCG, NCT);   // this work-group's column tiles
+  unsigned* const xmy = G > 1 ? a.xcnt + 32 * (size_t)g : nullptr;
+  unsigned xphase = 0;
 
   // ---------------------------------------------------------------- staging
   if (tid < R48_USERS) {
     const int usr = u0 + tid;
-    int t0 = 0;
+    int ts = 0;
     if (usr < a.B) {
       if (a.mode == 0) {
-        t0 = (int)a.t[usr];
+        ts = (int)a.t[usr];
       } else {
         const U4 w = philox4x32_10((uint32_t)(a.row0 + usr), 0u, PURPOSE_TRAIN_T, a.step, a.seed_lo, a.seed_hi);
-        t0 = 1 + (int)bounded(w.x, (uint32_t)a.T);
+        ts = 1 + (int)bounded(w.x, (uint32_t)a.T);
       }
-      t0 = min(max(t0, 0), a.T);
-      a.tdev[usr] = t0;
+      ts = min(max(ts, 0), a.T);
+      if (part == 0) a.tdev[usr] = ts;
     }
-    trow[tid] = t0;
+    trow[tid] = ts;
   }
   // thread -> (user tid >> 4, column quads (tid & 15) + 16 j): every x0 quad of the thread is requested before the first is used
   const int su = tid >> 4, sq = tid & 15;
@@ -81,7 +163,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
     xs[j] = (susr < a.B && c < a.L) ? load4_unpadded(a.x0, susr, c, a.L) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  const brsrc ures = make_brsrc(a.U + grow0 * a.K0, (uint32_t)(R48_ROWS * a.K0 * 4));
+  // (the layer-0 operand of the weight gradients is written by ONE work-group of the group: a zero-sized resource drops the others' stores)
+  const brsrc ures = make_brsrc(a.U + grow0 * a.K0, part == 0 ? (uint32_t)(R48_ROWS * a.K0 * 4) : 0u);
   {
     // the time-embedding columns of U, temb[t] of the row's timestep (read by the layer-0 weight gradient only: they deliver
     // M = dpre0^T * temb, tail.h; rows of users beyond the batch stay all-zero): the P, S and Q row of this thread's user
@@ -171,7 +254,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
   const uint32_t aoffl = (uint32_t)((li * LDA + lq) * 4);        // ... of the compact K-step's fragment (k = 16 ks + lq)
   const uint32_t lane16 = 16u * (uint32_t)lane;
   const int myrow = li;                            // + 16 rt: the lane's row of the tile; its user is u0 + li
-  const int mycol = 16 * CW * wc + 4 * lq;         // + 16 ct: the first of its four columns
+  const int wt0 = t0 + CW * wc;                    // the wave's first column tile
+  const int mycol = 16 * wt0 + 4 * lq;             // + 16 ct: the first of its four columns
   float* __restrict__ otile = Act + myrow * LDA + mycol;
   f32x4 acc[RT][CW];
   f32x4 b0[CW], b1[CW];
@@ -183,13 +267,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
   const int nlayers = a.H + 2;
   for (int layer = 0; layer < nlayers; ++layer) {
     const bool last = layer == nlayers - 1;
-    const brsrc Wf = make_brsrc((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)(CW * wc) * 256, (uint32_t)((KS * NCT - CW * wc) * 1024));
+    const brsrc Wf = make_brsrc((layer == 0 ? a.W0f : (last ? a.Wof : a.Whf)) + (size_t)wt0 * 256, (uint32_t)((KS * NCT - wt0) * 1024));
     // accumulators start at the bias (layer 0: the row's own row of b0 + C0[t]); tiles beyond the layer read the slack behind it
     {
       const float* bsrc = layer == 0 ? a.B0tab + (size_t)trow[myrow] * a.ldtab : (last ? a.bo : a.bh);
 #pragma unroll
       for (int ct = 0; ct < CW; ++ct) {
-        const bool tv = ALLV || CW * wc + ct < NCT;
+        const bool tv = ALLV || wt0 + ct < t1;
         const float4 bv = tv ? *reinterpret_cast<const float4*>(bsrc + mycol + 16 * ct) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = f32x4{bv.x, bv.y, bv.z, bv.w};
@@ -240,13 +324,33 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CW; ++ct) {
-          if (!ALLV && CW * wc + ct >= NCT) continue;   // (wave-uniform) a tile beyond the layer's columns
+          if (!ALLV && wt0 + ct >= t1) continue;   // (wave-uniform) a tile beyond the layer's / the work-group's columns
           const f32x4 v = acc[rt][ct];
           const float4 h = make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
           gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
           gstore4(aw + ct * 64, pbase + rt * prt, h);
           *reinterpret_cast<float4*>(otile + rt * R48_USERS * LDA + 16 * ct) = h;
         }
+    }
+    if constexpr (G > 1) {
+      // the other work-groups of the group hold the rest of the next layer's input: their stores of act[layer] have reached the
+      // XCD's L2 when the group has met; pull their column quads into the tile (every quad of a thread in flight before the wait)
+      ++xphase;
+      if (!r48_group_barrier(xmy, a.xbase + (unsigned)G * xphase, a.xabort, &go)) return;
+      const float* asrc = a.act + (size_t)layer * a.pre_stride + grow0 * a.ldp;
+      const int q0 = 4 * t0, q1 = 4 * t1;   // this work-group's own column quads
+      f32x4 pv[C::NPULL];
+#pragma unroll
+      for (int i = 0; i < C::NPULL; ++i) {
+        const int q = tid + NTHREADS * i, row = q / QP, cq = q - row * QP;
+        if (q < R48_ROWS * QP && (cq < q0 || cq >= q1)) pv[i] = r48_load_l2(asrc + (size_t)row * a.ldp + 4 * cq);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < C::NPULL; ++i) {
+        const int q = tid + NTHREADS * i, row = q / QP, cq = q - row * QP;
+        if (q < R48_ROWS * QP && (cq < q0 || cq >= q1)) *reinterpret_cast<f32x4*>(Act + row * LDA + 4 * cq) = pv[i];
+      }
     }
     __syncthreads();
   }
@@ -258,7 +362,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
   double sD = 0, sC = 0, sR = 0, sR2 = 0;
 #pragma unroll
   for (int ct = 0; ct < CW; ++ct) {
-    if (!ALLV && CW * wc + ct >= NCT) continue;
+    if (!ALLV && wt0 + ct >= t1) continue;
     const int col = mycol + 16 * ct;
     float fD = 0.f, fC = 0.f, fR = 0.f, fR2 = 0.f;
     float P[4], S[4], Q[4];
@@ -281,7 +385,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
   double tot[4] = {sD, sC, sR, sR2};
   block_sum4(tot, red);
   if (tid == 0) {
-    double* o = a.loss_part + 4 * (size_t)g;
+    double* o = a.loss_part + 4 * ((size_t)g * G + part);   // one partial per work-group: groups x G of them
     o[0] = tot[0]; o[1] = tot[1]; o[2] = tot[2]; o[3] = tot[3];
   }
 }
@@ -293,17 +397,32 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
 struct DgradChain48Args {
   DgradChainArgs c;
   int pad_rows;
+  // column-split row groups only: hand-shake counters (their own set: the forward's count on), number of row groups
+  unsigned* xcnt; unsigned xbase; unsigned* xabort; int ngroups;
 };
 
-template <int CT, bool LIGHT = false>
+// G > 1 (column-split row groups, see the head of this file): every work-group of a group computes the group's seeds itself (its
+// own copy of dY: the same values at the same addresses), owns 1 / G of every layer's output columns, and the group meets between
+// two layers - layer l + 1 reduces over ALL columns of layer l's output, which it then reads from the XCD's L2 (sc1 loads).
+template <int CT, bool LIGHT = false, int G = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradChain48Args ca) {
-  typedef Rows48Cfg<CT> C;
-  constexpr int CW = C::CW, NCT = C::NCT, NQ = C::NQ;
+  typedef Rows48Cfg<CT, G> C;
+  constexpr int CW = C::CW, NCT = C::NCT, NCG = C::NCG, NQ = C::NQ;
   __shared__ float red[4];
   __shared__ double shs[4], tot[4];
+  __shared__ int go;
   const DgradChainArgs& c = ca.c;
   const SeedArgs& a = c.seed;
-  const int tid = threadIdx.x, g = blockIdx.x;
+  const int tid = threadIdx.x;
+  int g = blockIdx.x, part = 0, ngroups = gridDim.x;
+  if constexpr (G > 1) {
+    const int slot = (int)blockIdx.x >> 3;
+    part = slot % G;
+    g = ((int)blockIdx.x & 7) + 8 * (slot / G);
+    ngroups = ca.ngroups;
+    if (g >= ngroups) return;
+  }
+  const int t0 = part * NCG, t1 = min(t0 + NCG, NCT);
   {
     // the five sums: given (sharded step, after the all-reduce) or folded here from the forward's per-work-group partials,
     // exactly as k_loss_seed does
@@ -328,7 +447,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradC
     const float cD = (float)(2.0 * k / N);
     const float cV = (float)(-(0.5 * (A + Cc) / (den * den)) * 2.0 / (N - 1.0));
     const float rbar = (float)Rbar;
-    if (g == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + Cc) / den);
+    if (g == 0 && part == 0 && tid == 0 && a.loss) *a.loss = (float)(0.5 * (A + Cc) / den);
     // thread -> (user tid / 16 of the group, column quads tid % 16 + 16 j)
     const int su = tid >> 4, sq = tid & 15, r = R48_USERS * g + su;
     const size_t rowP = (size_t)R48_ROWS * g + su;
@@ -370,9 +489,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradC
       *reinterpret_cast<float4*>(a.dY + yS) = make_float4(gS[0], gS[1], gS[2], gS[3]);
       *reinterpret_cast<float4*>(a.dY + yQ) = make_float4(gQ[0], gQ[1], gQ[2], gQ[3]);
     }
-    if (g == (int)gridDim.x - 1 && ca.pad_rows > 0) {
+    if (g == ngroups - 1 && part == 0 && ca.pad_rows > 0) {
       // the padding rows behind the last group: zero gradients in every buffer a weight gradient may read them from
-      const size_t r0 = (size_t)R48_ROWS * gridDim.x;
+      const size_t r0 = (size_t)R48_ROWS * ngroups;
       const int q4 = a.LP >> 2;
       for (int i = tid; i < ca.pad_rows * q4; i += NTHREADS)
         *reinterpret_cast<float4*>(a.dY + (r0 + i / q4) * a.LP + 4 * (i % q4)) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -383,9 +502,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradC
       }
     }
   }
+  unsigned* const xmy = G > 1 ? ca.xcnt + 32 * (size_t)g : nullptr;
   for (int l = 0; l < c.nlayers; ++l) {
-    __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
-    dr_layer<CW, LIGHT, R48_ROWS, NCT>(c.layer[l], g, red);
+    if constexpr (G > 1) {
+      if (l == 0) {
+        __syncthreads();   // this work-group's own copy of the seeds has landed
+        dr_layer<CW, LIGHT, R48_ROWS, NCT, true, 0>(c.layer[l], g, red, t0, t1, g * G + part);
+      } else {
+        // layer l - 1's output columns of the other work-groups of the group: in the XCD's L2 once the group has met
+        if (!r48_group_barrier(xmy, ca.xbase + (unsigned)G * (unsigned)l, ca.xabort, &go)) return;
+        dr_layer<CW, LIGHT, R48_ROWS, NCT, true, BUF_SC1>(c.layer[l], g, red, t0, t1, g * G + part);
+      }
+    } else {
+      __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
+      dr_layer<CW, LIGHT, R48_ROWS, NCT>(c.layer[l], g, red);
+    }
   }
 }
 

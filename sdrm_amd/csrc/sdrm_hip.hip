@@ -67,6 +67,9 @@ struct Tuning {
   int rows48 = 1;                // SDRM_ROWS48: the row-owned train step on 48-row work-groups (csrc/rows48.h: 16 users' P, S, Q rows; the
                                  // same nets as rowchain) for batches that do not fill the chip with 96-row work-groups: 0 never, 1 when
                                  // the batch's 16-user groups fill most of one round of the chip (see use_rows48), 2 whenever the net allows
+  int split = 1;                 // SDRM_ROWS48_SPLIT: column-split row groups of that step (G work-groups of one XCD share a 48-row group and
+                                 // exchange the activations through that XCD's L2, csrc/rows48.h) for batches of at most 2048 users:
+                                 // 0 never, 1 by size (see rows48_parts), 2 / 4: that many work-groups per group whenever the grid fits the chip
   int rowchain = 1;              // SDRM_ROWCHAIN: row-owned train forward (csrc/rowchain.h) for nets with L == W, padded width 128..352:
                                  // 0 never, 1 when the batch fills whole rounds of one 96-row work-group per CU, 2 whenever the net allows
 };
@@ -89,6 +92,15 @@ struct sdrm_engine {
   bool cur_sk = false;               // ... grouped by 16 users (the narrow nets' step, csrc/skinny_step.h)
   bool cur_g16 = false;              // ... grouped by 16 users by the 48-row row-owned forward (csrc/rows48.h)
   int cur_rows = 0;                  // stacked rows the last train_forward really wrote (whole groups; cur_MP rounds them up to the tile)
+  int cur_parts = 1;                 // work-groups per row group of that forward (csrc/rows48.h: 1, or 2 / 4 column-split)
+  // column-split row groups: hand-shake counters of the forward / of the dgrad chain [256 groups][32], never reset while the
+  // launch geometry stays the same (xgeo); the abort word lives in host-visible memory (xabort_host / its device alias)
+  unsigned *xcntF = nullptr, *xcntC = nullptr;
+  unsigned *xabort_host = nullptr, *xabort_dev = nullptr;
+  uint32_t xepochF = 0, xepochC = 0;
+  int xgeoF = 0, xgeoC = 0;           // (parts << 16 | groups) of the launches the counters have counted
+  bool xcd_ok = false;               // the probe launch of sdrm_create found work-group b on XCD b & 7
+  unsigned xskew = 0;                // test hook (sdrm_debug_split_skew): added once to the next split launch's counter base
   int cur_sk_np = 0;                 // ... and the loss partials its forward left (G, or 4 G: csrc/skinny_fwd4.h)
   bool tables_fresh = false;         // B0tab / the C0^T columns of W0c belong to the current parameters
   float* act = nullptr;              // activations prelu(pre[k]) [H+1][MPmax][WP], written by the row-owned forward beside pre[k]:
@@ -701,61 +713,129 @@ bool use_rowchain(const sdrm_engine* e, int B) {
   return rounds == 1 ? G >= 154 : G * 6 >= rounds * 256 * 5;
 }
 
-// The same step on 48-row work-groups (csrc/rows48.h), for batches the 96-row kernels would leave CUs idle with: the 16-user groups
-// of the batch should fill most of ONE round of the chip (two work-groups fit a CU, but the second round's worth then shares the
-// matrix pipes: no faster than the per-layer path).  Above 256 groups the 96-row kernels or the per-layer path take over.
-bool use_rows48(const sdrm_engine* e, int B) {
-  if (!e->W0f || e->tune.rows48 <= 0 || e->tune.force_cfg >= 0 || e->tune.rowchain >= 2) return false;
-  if (e->tune.rows48 >= 2) return true;
+// The same step on 48-row work-groups (csrc/rows48.h), for batches the 96-row kernels would leave CUs idle with.  Returns the
+// work-groups per 16-user row group, 0: not this path.
+//   1: the groups of the batch fill most of ONE round of the chip (176..256 groups: 2801..4096 users; two work-groups fit a CU, but
+//      a second round's worth then shares the matrix pipes: no faster than the per-layer path);
+//   2 / 4 (column-split groups, exchanged through one XCD's L2): batches of at most 2048 / 1024 users, whose groups x parts fit the
+//      chip's 256 CUs - every work-group of such a launch must be resident at once; by size only 2, for 1281 .. 2048 users.
+int rows48_grid(int groups, int parts) { return parts == 1 ? groups : 8 * parts * ((groups + 7) / 8); }
+int rows48_parts(const sdrm_engine* e, int B) {
+  if (!e->W0f || e->tune.rows48 <= 0 || e->tune.force_cfg >= 0 || e->tune.rowchain >= 2) return 0;
   const int G = (B + R48_USERS - 1) / R48_USERS;
-  return G >= 176 && G <= 256;
+  const bool can_split = e->xcd_ok && e->tune.split > 0 && e->xabort_host && *e->xabort_host == 0u;
+  if (can_split && e->tune.split >= 2) {
+    const int parts = e->tune.split >= 4 ? 4 : 2;
+    if (rows48_grid(G, parts) <= 256) return parts;
+    if (parts == 4 && rows48_grid(G, 2) <= 256) return 2;
+  }
+  if (e->tune.rows48 >= 2) return 1;
+  // (measured, tools/rows48_probe.py, profiles/r05_rows48_probe.txt: two work-groups per group beat the per-layer path from ~1300
+  // users on - B = 2048: 174 against 201 us, B = 1536: 164 against 170 - four per group do not: B = 1024: 140 against 131, the
+  // redundant staging and the two hand-shakes per kernel cost what the five launches saved)
+  if (can_split && e->tune.split == 1 && G > 80 && rows48_grid(G, 2) <= 256) return 2;       // 1281 .. 2048 users
+  return (G >= 176 && G <= 256) ? 1 : 0;
+}
+
+// the hand-shake counters of a column-split launch: they count on from launch to launch while the geometry stays the same
+int split_sync(sdrm_engine* e, bool chain, int groups, int parts, int phases, hipStream_t st, unsigned** cnt, unsigned* base) {
+  unsigned*& c = chain ? e->xcntC : e->xcntF;
+  uint32_t& epoch = chain ? e->xepochC : e->xepochF;
+  int& geo = chain ? e->xgeoC : e->xgeoF;
+  const int now = (parts << 16) | groups | (phases << 24);
+  if (geo != now || epoch >= 0x7fffffffu / (uint32_t)(phases * parts + 1)) {
+    HIP_TRY(e, hipMemsetAsync(c, 0, (size_t)256 * 32 * sizeof(unsigned), st));
+    epoch = 0; geo = now;
+  }
+  *cnt = c;
+  *base = epoch * (uint32_t)(phases * parts) + e->xskew;
+  if (e->xskew) { e->xskew = 0; geo = 0; }   // (the counters of a skewed launch are worthless: start over with the next one)
+  ++epoch;
+  return SDRM_OK;
+}
+
+// a timed-out hand-shake of an earlier column-split launch (csrc/rows48.h): reported by the next call, the path switched off
+int split_status(sdrm_engine* e) {
+  if (!e->xabort_host || *e->xabort_host == 0u) return SDRM_OK;
+  *e->xabort_host = 0u;   // reported once; the counters start over should the path ever be switched on again
+  e->xgeoF = e->xgeoC = 0;
+  e->tune.split = 0;
+  e->fwd_done = false;
+  return fail(e, SDRM_ERR_HIP, "a column-split row-group launch (csrc/rows48.h) timed out waiting for a work-group of its group: the results of "
+                               "that train step are invalid; the path is switched off for this handle");
+}
+
+template <int CT, int PARTS>
+int launch_rows48_forward_ctp(sdrm_engine* e, const RowChainArgs& a, int grid, hipStream_t st) {
+  if (a.light) SDRM_LAUNCH(e, (k_rows48_fwd<CT, true, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_rows48_fwd<CT, false, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+  return SDRM_OK;
 }
 
 template <int CT>
-int launch_rows48_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStream_t st) {
+int launch_rows48_forward_ct(sdrm_engine* e, RowChainArgs& a, int G, int parts, hipStream_t st) {
   const double flops = 2.0 * 3 * a.B * ((double)e->W * e->L + (double)e->H * e->W * e->W + (double)e->L * e->W);
   const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_ROW_FWD);
   size_t slot = 0;
+  if (parts > 1) {
+    if (int rc = split_sync(e, false, G, parts, e->H + 1, st, &a.xcnt, &a.xbase)) return rc;
+    a.xabort = e->xabort_dev; a.ngroups = G;
+  }
   if (rec) {
     slot = e->prof_cls.size();
     e->prof_cls.push_back(PC_ROW_FWD);
     e->prof_flops.push_back(flops);
     HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
   }
-  if (a.light) SDRM_LAUNCH(e, (k_rows48_fwd<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
-  else SDRM_LAUNCH(e, (k_rows48_fwd<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  const int grid = rows48_grid(G, parts);
+  if (parts == 4) launch_rows48_forward_ctp<CT, 4>(e, a, grid, st);
+  else if (parts == 2) launch_rows48_forward_ctp<CT, 2>(e, a, grid, st);
+  else launch_rows48_forward_ctp<CT, 1>(e, a, grid, st);
   HIP_TRY(e, hipGetLastError());
   if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
 }
 
+template <int CT, int PARTS>
+int launch_rows48_chain_ctp(sdrm_engine* e, const DgradChain48Args& a, int grid, hipStream_t st) {
+  if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, true, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+  else SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, false, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+  return SDRM_OK;
+}
+
 template <int CT>
-int launch_rows48_chain_ct(sdrm_engine* e, const DgradChain48Args& a, int G, double flops, hipStream_t st) {
+int launch_rows48_chain_ct(sdrm_engine* e, DgradChain48Args& a, int G, int parts, double flops, hipStream_t st) {
   const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_DGRAD_ROWS);
   size_t slot = 0;
+  if (parts > 1) {
+    if (int rc = split_sync(e, true, G, parts, std::max(1, a.c.nlayers - 1), st, &a.xcnt, &a.xbase)) return rc;
+    a.xabort = e->xabort_dev; a.ngroups = G;
+  }
   if (rec) {
     slot = e->prof_cls.size();
     e->prof_cls.push_back(PC_DGRAD_ROWS);
     e->prof_flops.push_back(flops);
     HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
   }
-  if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, true>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
-  else SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, false>), dim3((unsigned)G), dim3(NTHREADS), 0, st, a);
+  const int grid = rows48_grid(G, parts);
+  if (parts == 4) launch_rows48_chain_ctp<CT, 4>(e, a, grid, st);
+  else if (parts == 2) launch_rows48_chain_ctp<CT, 2>(e, a, grid, st);
+  else launch_rows48_chain_ctp<CT, 1>(e, a, grid, st);
   HIP_TRY(e, hipGetLastError());
   if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
   return SDRM_OK;
 }
 
-int launch_rows48_chain(sdrm_engine* e, const DgradChain48Args& a, int G, double flops, hipStream_t st) {
+int launch_rows48_chain(sdrm_engine* e, DgradChain48Args& a, int G, int parts, double flops, hipStream_t st) {
   switch (e->WP / 32) {
-    case 4: return launch_rows48_chain_ct<4>(e, a, G, flops, st);
-    case 5: return launch_rows48_chain_ct<5>(e, a, G, flops, st);
-    case 6: return launch_rows48_chain_ct<6>(e, a, G, flops, st);
-    case 7: return launch_rows48_chain_ct<7>(e, a, G, flops, st);
-    case 8: return launch_rows48_chain_ct<8>(e, a, G, flops, st);
-    case 9: return launch_rows48_chain_ct<9>(e, a, G, flops, st);
-    case 10: return launch_rows48_chain_ct<10>(e, a, G, flops, st);
-    default: return launch_rows48_chain_ct<11>(e, a, G, flops, st);
+    case 4: return launch_rows48_chain_ct<4>(e, a, G, parts, flops, st);
+    case 5: return launch_rows48_chain_ct<5>(e, a, G, parts, flops, st);
+    case 6: return launch_rows48_chain_ct<6>(e, a, G, parts, flops, st);
+    case 7: return launch_rows48_chain_ct<7>(e, a, G, parts, flops, st);
+    case 8: return launch_rows48_chain_ct<8>(e, a, G, parts, flops, st);
+    case 9: return launch_rows48_chain_ct<9>(e, a, G, parts, flops, st);
+    case 10: return launch_rows48_chain_ct<10>(e, a, G, parts, flops, st);
+    default: return launch_rows48_chain_ct<11>(e, a, G, parts, flops, st);
   }
 }
 
@@ -779,7 +859,7 @@ int launch_row_forward_ct(sdrm_engine* e, const RowChainArgs& a, int G, hipStrea
 }
 
 int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd, uint64_t seed,
-                       uint64_t step, float nd, int G, hipStream_t st, bool rows48 = false) {
+                       uint64_t step, float nd, int G, hipStream_t st, int rows48_parts_ = 0) {
   const int n = e->T + 1;
   RowChainArgs a{};
   a.x0 = x0;
@@ -794,16 +874,16 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
   a.act = e->act;
   a.loss_part = e->loss_part;
-  if (rows48) {
+  if (rows48_parts_ > 0) {
     switch (e->WP / 32) {
-      case 4: return launch_rows48_forward_ct<4>(e, a, G, st);
-      case 5: return launch_rows48_forward_ct<5>(e, a, G, st);
-      case 6: return launch_rows48_forward_ct<6>(e, a, G, st);
-      case 7: return launch_rows48_forward_ct<7>(e, a, G, st);
-      case 8: return launch_rows48_forward_ct<8>(e, a, G, st);
-      case 9: return launch_rows48_forward_ct<9>(e, a, G, st);
-      case 10: return launch_rows48_forward_ct<10>(e, a, G, st);
-      case 11: return launch_rows48_forward_ct<11>(e, a, G, st);
+      case 4: return launch_rows48_forward_ct<4>(e, a, G, rows48_parts_, st);
+      case 5: return launch_rows48_forward_ct<5>(e, a, G, rows48_parts_, st);
+      case 6: return launch_rows48_forward_ct<6>(e, a, G, rows48_parts_, st);
+      case 7: return launch_rows48_forward_ct<7>(e, a, G, rows48_parts_, st);
+      case 8: return launch_rows48_forward_ct<8>(e, a, G, rows48_parts_, st);
+      case 9: return launch_rows48_forward_ct<9>(e, a, G, rows48_parts_, st);
+      case 10: return launch_rows48_forward_ct<10>(e, a, G, rows48_parts_, st);
+      case 11: return launch_rows48_forward_ct<11>(e, a, G, rows48_parts_, st);
       default: return fail(e, SDRM_ERR_SHAPE, "row-owned forward: padded width outside 128..352");
     }
   }
@@ -1031,6 +1111,23 @@ int sdrm_debug_set_rows48(sdrm_engine* e, int mode) {
   return SDRM_OK;
 }
 
+int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode) {
+  if (!e) return SDRM_ERR_ARG;
+  if (e->bwd_begun) return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_rows48_split: between sdrm_train_backward_begin and _finish");
+  if (mode != 0 && mode != 1 && mode != 2 && mode != 4) return fail(e, SDRM_ERR_ARG, "sdrm_debug_set_rows48_split: 0, 1, 2 or 4");
+  e->fwd_done = false;
+  e->tune.split = mode;
+  return SDRM_OK;
+}
+
+int sdrm_debug_rows48_split_available(const sdrm_engine* e) { return e && e->W0f && e->xcd_ok ? 1 : 0; }
+
+int sdrm_debug_split_skew(sdrm_engine* e, unsigned skew) {
+  if (!e) return SDRM_ERR_ARG;
+  e->xskew = skew;
+  return SDRM_OK;
+}
+
 int sdrm_debug_rowchain_available(const sdrm_engine* e) { return e && e->W0f ? 1 : 0; }
 
 int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
@@ -1153,6 +1250,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_WGRAD_SLICES")) e->tune.wgrad_slices = std::min(S_MAX, std::max(0, std::atoi(env)));
   if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
   if (const char* env = std::getenv("SDRM_ROWS48")) e->tune.rows48 = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_ROWS48_SPLIT")) e->tune.split = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
   if (const char* env = std::getenv("SDRM_DGRAD_ROWS")) e->tune.dgrad_rows = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
@@ -1215,6 +1313,26 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->sel, 1));
   HIP_TRY(e, dalloc(&e->one_dev, 4));
   HIP_TRY(e, dalloc(&e->feed_flag, 4));
+  if (e->W0f) {
+    // column-split row groups (csrc/rows48.h): hand-shake counters, the host-visible abort word, and the check of the one property
+    // of the chip the path rests on - work-group b of a launch runs on XCD b & 7 - with a probe launch
+    HIP_TRY(e, dalloc(&e->xcntF, (size_t)256 * 32)); HIP_TRY(e, dalloc(&e->xcntC, (size_t)256 * 32));
+    HIP_TRY(e, hipHostMalloc((void**)&e->xabort_host, sizeof(unsigned), hipHostMallocMapped));
+    *e->xabort_host = 0u;
+    HIP_TRY(e, hipHostGetDevicePointer((void**)&e->xabort_dev, e->xabort_host, 0));
+    unsigned* probe = nullptr;
+    constexpr int NPROBE = 512;
+    HIP_TRY(e, dalloc(&probe, NPROBE));
+    hipLaunchKernelGGL(k_xcc_probe, dim3(NPROBE), dim3(64), 0, 0, probe);
+    std::vector<unsigned> xcc(NPROBE);
+    HIP_TRY(e, hipMemcpy(xcc.data(), probe, NPROBE * sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipFree(probe));
+    bool ok = true;
+    std::set<unsigned> ids;
+    for (int b = 0; b < NPROBE; ++b) ok = ok && (xcc[b] & 0xfu) == (xcc[b & 7] & 0xfu);
+    for (int x = 0; x < 8; ++x) ids.insert(xcc[x] & 0xfu);
+    e->xcd_ok = ok && ids.size() == 8;
+  }
   {
     const float one = 1.0f;
     HIP_TRY(e, hipMemcpy(e->one_dev, &one, 4, hipMemcpyHostToDevice));
@@ -1264,8 +1382,11 @@ int sdrm_destroy(sdrm_engine* e) {
                   e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->feed_flag, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (e->xcntF) (void)hipFree(e->xcntF);
+  if (e->xcntC) (void)hipFree(e->xcntC);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   (void)hipDeviceSynchronize();
+  if (e->xabort_host) (void)hipHostFree(e->xabort_host);
   (void)sdrm_comm_destroy(e);
   for (float* b : e->dec_buf)
     if (b) (void)hipFree(b);
@@ -1357,7 +1478,8 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
 
-  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false; e->cur_g16 = false; e->cur_rows = MP;
+  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false; e->cur_g16 = false; e->cur_rows = MP; e->cur_parts = 1;
+  if (int xs = split_status(e)) return xs;
   if (skinny_net(e)) {
     // narrow net (csrc/skinny_step.h): staging, all layers and the loss partial sums of 16 users' P, S, Q rows per work-group in
     // ONE launch; the tables B0tab = b0 + C0[t] come from the last step's tail (or are made now, after a parameter upload)
@@ -1406,19 +1528,20 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     return SDRM_OK;
   }
 
-  if (use_rows48(e, B)) {
-    // the same on 48-row work-groups (rows48.h): tables, then ONE launch
+  if (const int parts = rows48_parts(e, B)) {
+    // the same on 48-row work-groups (rows48.h; `parts` of them per row group): tables, then ONE launch
     int rc = emb_tables(e, st, x0, (size_t)B * e->L);
     if (rc) return rc;
     const int G = (B + R48_USERS - 1) / R48_USERS, MPg = round_up(G * R48_ROWS, BM);
-    rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st, true);
+    rc = launch_row_forward(e, x0, B, row0, mode, rnd, seed, step, nd, G, st, parts);
     if (rc) return rc;
     if (!e->fold_sums) {
-      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, G, (double)B * (double)e->L,
+      SDRM_LAUNCH(e, k_loss_sums, dim3(1), dim3(256), 0, st, (const double*)e->loss_part, G * parts, (double)B * (double)e->L,
                          sums ? sums : e->sums);
       HIP_TRY(e, hipGetLastError());
     }
-    e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * R48_ROWS; e->cur_x0 = x0; e->cur_g16 = true; e->cur_act = true; e->fwd_done = true;
+    e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * R48_ROWS; e->cur_x0 = x0; e->cur_g16 = true; e->cur_parts = parts; e->cur_act = true;
+    e->fwd_done = true;
     return SDRM_OK;
   }
 
@@ -1491,7 +1614,7 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
   sa.sums = e->fold_sums ? nullptr : (sums ? sums : e->sums); sa.Y = e->Y; sa.x0 = e->cur_x0; sa.dY = e->dY; sa.loss = loss;
   sa.B = B; sa.L = e->L; sa.LP = e->LP; sa.MP = MP; sa.grouped = (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0);
   sa.part = e->loss_part;
-  sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : (e->cur_g16 ? (B + R48_USERS - 1) / R48_USERS : LOSS_BLOCKS);
+  sa.nblk = e->cur_grouped ? (B + RC_USERS - 1) / RC_USERS : (e->cur_g16 ? e->cur_parts * ((B + R48_USERS - 1) / R48_USERS) : LOSS_BLOCKS);
   sa.count = (double)B * (double)e->L;
   // the row-owned chain (dgrad_rows.h) computes the seeds itself; every other path launches k_loss_seed
   const bool chain48 = e->cur_g16 && e->WhfT && e->tune.dgrad_rows > 0 && e->LP == e->WP && H + 1 <= DR_MAX_LAYERS;
@@ -1540,13 +1663,13 @@ int backward_chain(sdrm_engine* e, const double* sums, float* loss, hipStream_t 
                                             e->alpha_part + (size_t)(k - 1) * e->alpha_part_stride);
     const int Gn = e->cur_rows / R48_ROWS;
     c8.pad_rows = MP - e->cur_rows;
-    int rc = launch_rows48_chain(e, c8, Gn, flO + H * flH, st);
+    int rc = launch_rows48_chain(e, c8, Gn, e->cur_parts, flO + H * flH, st);
     if (rc) return rc;
     if (with_wgrad0)
       HIP_TRY(e, (gemm_wgrad<XF_NONE>(dpre_buf(e, 0), e->WP, e->WP, e->U, e->K0, e->K0, nullptr, MP, S0, kc0, e->slab0, e->db0s, st,
                                       Prof{e, PC_WGRAD_L0, fl0}, cfg_w)));
     e->bwd_kc0 = kc0;
-    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = Gn;
+    e->bwd_S0 = S0; e->bwd_SH = SH; e->bwd_SO = SO; e->bwd_dgrad_blocks = Gn * e->cur_parts;
     e->bwd_kcH = kcH; e->bwd_kcO = kcO;
     return SDRM_OK;
   }

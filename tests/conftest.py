@@ -40,6 +40,13 @@ def engine_cls():
 
     class TestEngine(Engine):
         def debug_set(self, **kw):
+            if kw.get("tile") in ("row48x2", "row48x4"):
+                # ... with 2 / 4 work-groups of one XCD per row group (column-split, exchanged through that XCD's L2); batches whose
+                # groups x parts do not fit the chip fall back to fewer parts (csrc/sdrm_hip.hip: rows48_parts)
+                if not self.rows48_split_available:
+                    self.close()
+                    pytest.skip("shape outside the row-owned forward's envelope (or no block -> XCD mapping)")
+                kw = dict(kw, tile=None, rowchain=0, rows48=2, rows48_split=int(kw["tile"][-1]), wgrad_strips=True, dgrad_rows=1)
             if kw.get("tile") in ("row48", "row48-tiles"):
                 # the row-owned step on 48-row work-groups (csrc/rows48.h) forced on: "row48" with its dgrad chain and the strip-owned
                 # weight gradients behind it, "row48-tiles" the same forward with k_loss_seed + tile dgrads + batched tile weight gradients
@@ -47,7 +54,7 @@ def engine_cls():
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope")
                 mode = kw["tile"]
-                kw = dict(kw, tile=None, rowchain=0, rows48=2, wgrad_strips=mode == "row48", dgrad_rows=1 if mode == "row48" else 0)
+                kw = dict(kw, tile=None, rowchain=0, rows48=2, rows48_split=0, wgrad_strips=mode == "row48", dgrad_rows=1 if mode == "row48" else 0)
             if kw.get("tile") in ("row", "row-layers", "row-tiles"):
                 if not self.rowchain_available:
                     self.close()

@@ -41,7 +41,7 @@ def sampler_path(request):
 
 TILES = [-1, 0, 4]   # automatic; forced 64x64x16 (32-wide MFMA); forced 32x32x32 (16-wide MFMA): every step-level test
                      # below runs on each, so a size-threshold retune cannot change which kernels the suite covers
-ROW_PATHS = ["row", "row-layers", "row-tiles", "row48", "row48-tiles"]   # the row-owned forwards: 96-row work-groups (csrc/rowchain.h) with each
+ROW_PATHS = ["row", "row-layers", "row-tiles", "row48", "row48-tiles", "row48x2", "row48x4"]   # the row-owned forwards: 96-row work-groups (csrc/rowchain.h) with each
                      # backward behind them, 48-row work-groups (csrc/rows48.h) with their own chain + strips, or with the tile backward
 TRAIN_PATHS = TILES + ROW_PATHS   # train-step tests also run through the row-owned forwards (grouped row orders)
 
@@ -475,7 +475,7 @@ def test_backward_forms_behind_the_row_owned_forward(engine_cls, dims):
 
     ref = grads(-1)
     for path, two_call in (("row", False), ("row-layers", False), ("row-tiles", False), ("row", True), ("row48", False), ("row48-tiles", False),
-                           ("row48", True)):
+                           ("row48", True), ("row48x2", False), ("row48x4", False), ("row48x4", True)):
         loss, g, p = grads(path, two_call)
         assert abs(loss - ref[0]) <= 1e-5 * abs(ref[0])
         for (n, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(ref[1], (L, W, T, H))):
@@ -720,3 +720,36 @@ def test_error_behaviour(engine_cls):
     with pytest.raises(SdrmError):
         engine_cls(0, 16, 5, 1, 4)
     e.close()
+
+
+def test_split_row_groups_time_out_instead_of_hanging(engine_cls):
+    """csrc/rows48.h, column-split row groups: the only inter-work-group wait in a product kernel.  Every wait is bounded by the wall
+    clock: a launch whose groups can never meet (fault injection: its counter base is moved out of reach) ends by itself in ~30 ms,
+    the handle reports SDRM_ERR_HIP at the next train call - once - and carries on, on the per-layer path, with correct results."""
+    import time
+    import torch
+    from sdrm_amd.engine import SdrmError
+    L, W, T, H, B = 136, 136, 12, 1, 300
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=31), H)
+    x0 = synth.synth_latents(B, L, seed=32)
+    eps, t, keep = synth.synth_train_randoms(B, L, T, 0.9, seed=33)
+    e = engine_cls(L, W, T, H, B).debug_set(tile="row48x2")
+    ref = engine_cls(L, W, T, H, B).debug_set(tile=-1)
+    for eng in (e, ref):
+        eng.set_params(init)
+    la = float(e.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())     # a healthy split step first
+    lb = float(ref.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    e._check(e.lib.sdrm_debug_split_skew(e._h, 1 << 20), "sdrm_debug_split_skew")
+    t0 = time.time()
+    e.train_forward(x0, noise=eps, t=t, keep=keep)                          # its hand-shakes cannot complete
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0                                           # bounded: no watchdog needed
+    with pytest.raises(SdrmError, match="timed out"):
+        e.train_step(x0, 1e-3, noise=eps, t=t, keep=keep)
+    e.set_params(init); ref.set_params(init)
+    e.adam_reset(); ref.adam_reset()
+    la = float(e.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())     # the handle goes on, without the split path
+    lb = float(ref.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
+    assert abs(la - lb) <= 1e-5 * abs(lb) and rel_l2(e.get_params().cpu().numpy(), ref.get_params().cpu().numpy()) <= 1e-5
+    e.close(); ref.close()

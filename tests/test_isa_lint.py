@@ -88,16 +88,21 @@ def test_row_owned_kernels_isa(ct):
                    f"template __global__ void sdrm::k_row_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n"
                    # the same step on 48-row work-groups (csrc/rows48.h): the same asm MFMAs through the same K-step templates
                    f"template __global__ void sdrm::k_rows48_fwd<{ct}, {light}>(const sdrm::RowChainArgs);\n"
-                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}>(const sdrm::DgradChain48Args);\n")
+                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}>(const sdrm::DgradChain48Args);\n"
+                   # ... and with two work-groups per row group (column-split, the form the size rule takes for 1281 .. 2048 users)
+                   f"template __global__ void sdrm::k_rows48_fwd<{ct}, {light}, 2>(const sdrm::RowChainArgs);\n"
+                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}, 2>(const sdrm::DgradChain48Args);\n")
     ks = _kernels(asm)
     names = {"chain": [n for n in ks if "k_dgrad_chain" in n and "rows48" not in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
-             "fwd": [n for n in ks if "k_row_fwd" in n], "fwd48": [n for n in ks if "k_rows48_fwd" in n],
-             "chain48": [n for n in ks if "k_rows48_dgrad_chain" in n]}
+             "fwd": [n for n in ks if "k_row_fwd" in n], "fwd48": [n for n in ks if "k_rows48_fwd" in n and "ELi2E" not in n],
+             "chain48": [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi2E" not in n],
+             "fwd48x2": [n for n in ks if "k_rows48_fwd" in n and "ELi2E" in n],
+             "chain48x2": [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi2E" in n]}
     assert all(len(v) == 1 for v in names.values()), names
     for kind, (name,) in names.items():
         ins = ks[name]
         mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma")]
-        assert len(mf) >= (100 if "48" not in kind else 48), (kind, len(mf))
+        assert len(mf) >= (100 if "48" not in kind else 12), (kind, len(mf))
         # K loops: the loops that hold MFMAs
         loops = _loops(ins)
         inner = [(a, b) for a, b in loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in loops)]

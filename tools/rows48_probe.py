@@ -14,10 +14,14 @@ from sdrm_amd.engine import Engine  # noqa: E402
 
 L, W, T, H = 340, 340, 78, 1
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-MODES = {"tiles": dict(rowchain=0, rows48=0), "rows96": dict(rowchain=2, rows48=0), "rows48": dict(rowchain=0, rows48=2),
-         "rows48+tile-bwd": dict(rowchain=0, rows48=2, dgrad_rows=0, wgrad_strips=0), "auto": dict()}
+MODES = {"tiles": dict(rowchain=0, rows48=0), "rows96": dict(rowchain=2, rows48=0), "rows48": dict(rowchain=0, rows48=2, rows48_split=0),
+         "x2": dict(rowchain=0, rows48=2, rows48_split=2), "x2+tile-wgrad": dict(rowchain=0, rows48=2, rows48_split=2, wgrad_strips=0),
+         "x4": dict(rowchain=0, rows48=2, rows48_split=4), "x4+tile-wgrad": dict(rowchain=0, rows48=2, rows48_split=4, wgrad_strips=0),
+         "auto": dict()}
+if len(sys.argv) > 2:
+    MODES = {k: v for k, v in MODES.items() if k in sys.argv[2].split(",")}
 init = synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H)
-for B in (1024, 2048, 2816, 3072, 4096, 5120, 6144, 8192):
+for B in [int(b) for b in sys.argv[3].split(',')] if len(sys.argv) > 3 else (512, 768, 1024, 1536, 2048, 2816, 3072, 4096, 5120, 6144, 8192):
     x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)).cuda()
     line = []
     for name, kw in MODES.items():
