@@ -156,6 +156,7 @@ OTHER = {   # BASELINE.json configs besides the benched one (README hyper-parame
     # the batch sweep of C3 (160, 512, 2048, 8192): train step only - the sampled rows are the same
     "ML-1M/MLP    B=512 L=340 T=78 H=1 (batch sweep)": dict(L=340, W=340, T=78, H=1, B=512, n=0),
     "ML-1M/MLP    B=2048 L=340 T=78 H=1 (batch sweep)": dict(L=340, W=340, T=78, H=1, B=2048, n=0),
+    "ML-1M/MLP    B=4096 L=340 T=78 H=1 (batch sweep; the 2-GPU shard of the 8192 batch)": dict(L=340, W=340, T=78, H=1, B=4096, n=0),
     "ADM/NeuMF    B=850 L=40 T=93 H=5 n=9558": dict(L=40, W=40, T=93, H=5, B=850, n=9558),
 }
 

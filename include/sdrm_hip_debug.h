@@ -61,6 +61,14 @@ int sdrm_debug_set_rows48(sdrm_engine* e, int mode);
  * call on the handle as SDRM_ERR_HIP and switches the path off for the handle. */
 int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode);
 int sdrm_debug_rows48_split_available(const sdrm_engine* e);
+/* Reverse-sampling steps without kernel boundaries between the layers (csrc/sample_persist.h: one launch per sdrm_sample_steps call
+ * runs its `count` steps - every layer on the 32x32 tile, the reverse update in the out layer's epilogue - with the column tiles of
+ * a row tile synchronised through ONE XCD's L2): full-resolution PHILOX sampling of a net with L == W; 0 never, 1 (default) for at
+ * most 352 rows (one work-group per CU: measured 12.1 against 16.5 us per step at 339 rows; at 679 rows - the 8-GPU shard of the 5429
+ * sampled users - the fullest XCDs hold 33 work-groups for 32 CUs and it ties, 16.0 against 16.4), 2 whenever every work-group of the launch is resident at once
+ * (at most two 32x32 tiles per CU on the fullest XCD); also env SDRM_SAMPLE_PERSIST.  Results are those of the per-layer path with
+ * the fused reverse update (same tile body, same epilogue).  Refused inside a sampling call. */
+int sdrm_debug_set_sample_persist(sdrm_engine* e, int mode);
 /* Fault injection for that path: the NEXT column-split launch waits for a count its group never reaches (its base is moved up by
  * `skew`), so every work-group of it runs into the 30 ms bound of its first hand-shake, raises the abort word and returns; the
  * next train call on the handle then reports SDRM_ERR_HIP and the handle continues on the per-layer path. */

@@ -167,14 +167,15 @@ template <int LOAD, int ROWS, int BK>
 __device__ __forceinline__ brsrc tile_resource(const float* __restrict__ src, int ld, int i0, int kb) {
   return make_brsrc(LOAD == LD_KCONTIG ? src + (size_t)i0 * ld + kb : src + (size_t)kb * ld + i0, 0xffffffffu);
 }
-template <int LOAD, int ROWS, int BK>
+// AUX: cache-policy bits of the loads (bufres.h; BUF_SC1 where another work-group of the SAME launch wrote the operand: csrc/sample_persist.h)
+template <int LOAD, int ROWS, int BK, int AUX = 0>
 __device__ __forceinline__ void load_tile(brsrc res, const uint32_t (&vo)[ROWS * BK / 4 / NTHREADS], int ld, int k0 /* from the resource's first k */,
                                           float4 (&r)[ROWS * BK / 4 / NTHREADS]) {
   constexpr int NV = ROWS * BK / 4 / NTHREADS;
   const uint32_t so = (LOAD == LD_KCONTIG ? (uint32_t)k0 : (uint32_t)k0 * (uint32_t)ld) * 4u;
 #pragma unroll
   for (int s = 0; s < NV; ++s) {
-    const f32x4_b v = bload4(res, vo[s], so);
+    const f32x4_b v = bload4a<AUX>(res, vo[s], so);
     r[s] = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
@@ -273,8 +274,9 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, K * 0x55, 0xF, 0xF, true);
 }
 
-template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI>
-__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
+// COHA: cache policy of the A operand's loads; logical_in >= 0: the caller's tile index (instead of the XCD remap of `bid`).
+template <class Cfg, int LOADA, int LOADB, int XFA, int XFB, int EPI, int COHA = 0>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, const int logical_in = -1) {
   constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, TM = Cfg::TM, TN = Cfg::TN, MF = Cfg::MF;
   constexpr int NR = (MF == 32) ? 16 : 4;      // accumulator registers per MFMA tile
   constexpr int KG = (MF == 32) ? 2 : 4;       // k consumed by one MFMA
@@ -330,7 +332,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
     split = div_magic(u, p.magic_nblocks);
     logical = u - split * p.nblocks;
   } else {
-    logical = xcd_remap(bid, p.nblocks);
+    logical = logical_in >= 0 ? logical_in : xcd_remap(bid, p.nblocks);
     split = 0;
   }
   const int tile_m = div_magic(logical, p.magic_tiles_n), tile_n = logical - tile_m * p.tiles_n;
@@ -365,7 +367,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
   tile_offsets<LOADB, BN, BK>(p.ldb, voB, tid);
   auto ld = [&](float4 (&xa)[NVA], float4 (&xb)[NVB], int i) {
     const int k0 = kb + min(i, nt - 1) * BK;   // past the end: re-read the last K-step (never consumed)
-    load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa);
+    load_tile<LOADA, BM, BK, COHA>(resA, voA, p.lda, k0 - kb, xa);
     load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb);
   };
   auto st = [&](const float4 (&xa)[NVA], const float4 (&xb)[NVB], int stage) {
@@ -498,7 +500,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
           if constexpr (XFA == XF_PRELU) DIAG_ST((store_tile_km<XF_NONE, BM, LDK, BK>(Aw, xa, 0.f, tid)));
           DIAG_ST((store_tile_km<XFB, BN, LDK, BK>(Aw + BOFF, xb, slopeB, tid)));
         } else if (sl == 2 * NQ + 2) {
-          DIAG_LD((load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa)));
+          DIAG_LD((load_tile<LOADA, BM, BK, COHA>(resA, voA, p.lda, k0 - kb, xa)));
         } else if (sl == 2 * NQ + 3) {
           DIAG_LD((load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb)));
         }
@@ -597,7 +599,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid) {
         }
         if (g == G / 2) store_tile<LOADA, XFA, BM, LDA, BK>(Aw, xa, slopeA, tid);
         else if (g == G / 2 + 1) store_tile<LOADB, XFB, BN, LDB, BK>(Aw + BOFF, xb, slopeB, tid);
-        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK>(resA, voA, p.lda, k0 - kb, xa);
+        else if (g == G / 2 + 2) load_tile<LOADA, BM, BK, COHA>(resA, voA, p.lda, k0 - kb, xa);
         else if (g == G / 2 + 3) load_tile<LOADB, BN, BK>(resB, voB, p.ldb, k0 - kb, xb);
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -22,6 +22,7 @@
 #include "rank.h"
 #include "rowchain.h"
 #include "rows48.h"
+#include "sample_persist.h"
 #include "select.h"
 #include "skinny.h"
 #include "skinny_step.h"
@@ -67,6 +68,8 @@ struct Tuning {
   int rows48 = 1;                // SDRM_ROWS48: the row-owned train step on 48-row work-groups (csrc/rows48.h: 16 users' P, S, Q rows; the
                                  // same nets as rowchain) for batches that do not fill the chip with 96-row work-groups: 0 never, 1 when
                                  // the batch's 16-user groups fill most of one round of the chip (see use_rows48), 2 whenever the net allows
+  int smp_persist = 1;           // SDRM_SAMPLE_PERSIST: reverse steps without kernel boundaries between the layers (csrc/sample_persist.h; full
+                                 // resolution, PHILOX, L == W, one row chain): 0 never, 1 for at most SMP_PERSIST_MAX_ROWS (352) rows, 2 whenever it fits
   int split = 1;                 // SDRM_ROWS48_SPLIT: column-split row groups of that step (G work-groups of one XCD share a 48-row group and
                                  // exchange the activations through that XCD's L2, csrc/rows48.h) for batches of at most 2048 users:
                                  // 0 never, 1 by size (see rows48_parts), 2 / 4: that many work-groups per group whenever the grid fits the chip
@@ -100,6 +103,8 @@ struct sdrm_engine {
   uint32_t xepochF = 0, xepochC = 0;
   int xgeoF = 0, xgeoC = 0;           // (parts << 16 | groups) of the launches the counters have counted
   bool xcd_ok = false;               // the probe launch of sdrm_create found work-group b on XCD b & 7
+  unsigned* xcntS = nullptr;         // the persistent sampler's row-tile counters [256][32] and what they stand at (phases x column tiles)
+  uint32_t xphaseS = 0;
   unsigned xskew = 0;                // test hook (sdrm_debug_split_skew): added once to the next split launch's counter base
   int cur_sk_np = 0;                 // ... and the loss partials its forward left (G, or 4 G: csrc/skinny_fwd4.h)
   bool tables_fresh = false;         // B0tab / the C0^T columns of W0c belong to the current parameters
@@ -182,7 +187,7 @@ struct sdrm_engine {
 typedef sdrm_engine::SampleStateT SampleState;
 
 enum ProfClass { PC_FWD_L0 = 0, PC_FWD_HIDDEN, PC_FWD_OUT, PC_DGRAD, PC_WGRAD, PC_WGRAD_L0, PC_SMP_L0, PC_SMP_HIDDEN,
-                 PC_SMP_OUT, PC_ROW_FWD, PC_WGRAD_STRIPS, PC_DGRAD_ROWS, PC_COUNT };
+                 PC_SMP_OUT, PC_ROW_FWD, PC_WGRAD_STRIPS, PC_DGRAD_ROWS, PC_SMP_PERSIST, PC_COUNT };
 // the template arguments are <LOADA,LOADB,XFA,XFB,EPI> of gemm_kernel (what rocprofv3 prints after the tile type)
 static const char* kProfNames[PC_COUNT] = {
     "train: gemm_kernel<0,0,0,0,9> fwd layer0 (row-table bias)", "train: gemm_kernel<0,0,1,0,0> fwd hidden (prelu-in, bias)",
@@ -194,7 +199,8 @@ static const char* kProfNames[PC_COUNT] = {
     "sample: gemm_kernel<0,0,0,0,1> fwd out (tanh)",
     "train: k_row_fwd row-owned forward (staging + all layers + loss partial sums, one work-group per CU)",
     "train: k_wgrad_strips weight gradients of all layers (strip-owned split-K, one work-group per CU)",
-    "train: k_dgrad_chain / k_dgrad_rows input gradients (row-owned, prelu' epilogue, one work-group per CU; the chain: loss seeds + every layer in one launch)"};
+    "train: k_dgrad_chain / k_dgrad_rows input gradients (row-owned, prelu' epilogue, one work-group per CU; the chain: loss seeds + every layer in one launch)",
+    "sample: k_sample_persist reverse steps without kernel boundaries (all layers + reverse update per step, row tiles synchronised through one XCD's L2)"};
 
 namespace {
 
@@ -1122,6 +1128,13 @@ int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode) {
 
 int sdrm_debug_rows48_split_available(const sdrm_engine* e) { return e && e->W0f && e->xcd_ok ? 1 : 0; }
 
+int sdrm_debug_set_sample_persist(sdrm_engine* e, int mode) {
+  if (!e) return SDRM_ERR_ARG;
+  if (e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_sample_persist: inside a sampling call");
+  e->tune.smp_persist = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  return SDRM_OK;
+}
+
 int sdrm_debug_split_skew(sdrm_engine* e, unsigned skew) {
   if (!e) return SDRM_ERR_ARG;
   e->xskew = skew;
@@ -1251,6 +1264,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_ROWCHAIN")) e->tune.rowchain = std::atoi(env);
   if (const char* env = std::getenv("SDRM_ROWS48")) e->tune.rows48 = std::atoi(env);
   if (const char* env = std::getenv("SDRM_ROWS48_SPLIT")) e->tune.split = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_SAMPLE_PERSIST")) e->tune.smp_persist = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
   if (const char* env = std::getenv("SDRM_DGRAD_ROWS")) e->tune.dgrad_rows = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;
@@ -1317,6 +1331,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
     // column-split row groups (csrc/rows48.h): hand-shake counters, the host-visible abort word, and the check of the one property
     // of the chip the path rests on - work-group b of a launch runs on XCD b & 7 - with a probe launch
     HIP_TRY(e, dalloc(&e->xcntF, (size_t)256 * 32)); HIP_TRY(e, dalloc(&e->xcntC, (size_t)256 * 32));
+    HIP_TRY(e, dalloc(&e->xcntS, (size_t)256 * 32));
     HIP_TRY(e, hipHostMalloc((void**)&e->xabort_host, sizeof(unsigned), hipHostMallocMapped));
     *e->xabort_host = 0u;
     HIP_TRY(e, hipHostGetDevicePointer((void**)&e->xabort_dev, e->xabort_host, 0));
@@ -1384,6 +1399,7 @@ int sdrm_destroy(sdrm_engine* e) {
     if (b) (void)hipFree(b);
   if (e->xcntF) (void)hipFree(e->xcntF);
   if (e->xcntC) (void)hipFree(e->xcntC);
+  if (e->xcntS) (void)hipFree(e->xcntS);
   for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
   (void)hipDeviceSynchronize();
   if (e->xabort_host) (void)hipHostFree(e->xabort_host);
@@ -2279,8 +2295,75 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   SDRM_LAUNCH(e, k_sample_init, grid, dim3(256), 0, st, ia);
   HIP_TRY(e, hipGetLastError());
   e->smp = SampleState{true, n, MP, multires, mode, i_start, nd, z, keep, seed, call_id, row0, xT, false, false, i_start};
+  if (e->xcntS) {   // the persistent sampler's counters start every call at zero (row tiles differ from call to call)
+    HIP_TRY(e, hipMemsetAsync(e->xcntS, 0, (size_t)256 * 32 * sizeof(unsigned), st));
+    e->xphaseS = 0;
+  }
   return SDRM_OK;
 }
+
+namespace {
+// Reverse steps in one launch (csrc/sample_persist.h): full resolution, PHILOX (the reverse update rides in the out layer's
+// epilogue), a net whose layers share one tiling (L == W), one row chain, a forced tile only if it is the 32x32 one, the chip's
+// block -> XCD mapping, and every work-group resident at once: 32x32 tiles, at most two per CU on the fullest XCD.
+// by size: up to 11 row tiles of 32 (at most two row tiles = 22 work-groups per XCD: one per CU).  Measured (tools/sample_persist_probe.py,
+// profiles/r05_sample_persist_probe.txt): n = 339: 12.1 us per step for a whole call in one launch against 16.5 for the three
+// launches per step (15.7 driven one step per call); n = 679 - the 8-GPU shard: 22 row tiles put 33 work-groups on six XCDs' 32
+// CUs, the doubled CU sets every phase - 16.0 against 16.4 (19.9 one step per call), n = 1024: 18.8 against 17.7: not taken there
+constexpr int SMP_PERSIST_MAX_ROWS = 352;
+bool sample_persist_fits(const sdrm_engine* e, const SampleState& s) {
+  if (e->tune.smp_persist <= 0 || !e->xcd_ok || !e->xcntS || !e->xabort_host || *e->xabort_host != 0u) return false;
+  if (s.multires || s.mode != SDRM_RNG_PHILOX || e->LP != e->WP || e->n_chains != 1) return false;
+  if (e->tune.force_cfg >= 0 && e->tune.force_cfg != 4) return false;
+  if (e->tune.fuse_rev == 0) return false;   // (a caller who asked for the stand-alone reverse update gets the per-layer path)
+  const int tiles_m = s.MP / 32, tiles_n = e->WP / 32;
+  const int per_xcd = ((tiles_m + 7) / 8) * tiles_n;
+  if (per_xcd > 64 || tiles_m > 256) return false;
+  return e->tune.smp_persist >= 2 || s.n <= SMP_PERSIST_MAX_ROWS;
+}
+
+int launch_sample_persist(sdrm_engine* e, SampleState& s, int count, hipStream_t st) {
+  const NetView nv = snapshot_view(e);
+  const int MP = s.MP, tiles_m = MP / 32, tiles_n = e->WP / 32;
+  SamplePersistArgs P{};
+  auto layer = [&](GemmArgs& a, const float* A, int lda, const float* Wc, int ldw, float* C, int ldc, int K) {
+    a.A = A; a.lda = lda; a.limA = MP; a.B = Wc; a.ldb = ldw; a.limB = e->WP; a.K = K; a.kchunk = K; a.C = C; a.ldc = ldc;
+    return gemm_set_grid(a, tiles_m, tiles_n, 1);
+  };
+  bool ok = layer(P.l0, e->Us, e->LP, nv.W0c, e->K0, pre_buf(e, 0), e->WP, e->LP);
+  P.l0.slopeE = nv.slope0;
+  ok = ok && layer(P.lh, pre_buf(e, 0), e->WP, nv.Whc, e->WP, pre_buf(e, 1), e->WP, e->WP);
+  P.lh.bias = nv.bhc; P.lh.slopeE = nv.slopeh;
+  ok = ok && layer(P.lo, pre_buf(e, e->H), e->WP, nv.Woc, e->WP, e->Y, e->LP, e->WP);
+  if (!ok) return fail(e, SDRM_ERR_SHAPE, "persistent sampler: grid beyond the tile arithmetic");
+  GemmArgs& a = P.lo;
+  a.bias = nv.boc; a.rows_valid = MP; a.cols_valid = e->LP;
+  a.revX = e->X; a.revU = e->Us; a.rev_ldx = e->LP; a.rev_s0 = 0; a.rev_n = s.n; a.rev_L = e->L; a.rev_nd = s.nd;
+  a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id; a.rev_row0 = s.row0;
+  P.pre_stride = (size_t)e->MPmax * e->WP;
+  P.B0tab = nv.B0tab; P.ldtab = e->WP; P.rev = e->rev_dev;
+  P.T = e->T; P.H = e->H; P.i_first = s.i_next; P.count = count;
+  P.row_tiles = tiles_m; P.tiles_n = tiles_n;
+  P.cnt = e->xcntS; P.base = e->xphaseS * (uint32_t)tiles_n; P.abort_ = e->xabort_dev;
+  const int steps = std::min(count, s.i_next);
+  e->xphaseS += (uint32_t)(steps * (e->H + 2));
+  const int grid = 8 * tiles_n * ((tiles_m + 7) / 8);
+  const double flops = 2.0 * s.n * ((double)e->W * e->L + (double)e->H * e->W * e->W + (double)e->L * e->W) * steps;
+  const bool rec = e->prof_on && (int)e->prof_cls.size() < e->prof_cap && (e->prof_only < 0 || e->prof_only == PC_SMP_PERSIST);
+  size_t slot = 0;
+  if (rec) {
+    slot = e->prof_cls.size();
+    e->prof_cls.push_back(PC_SMP_PERSIST);
+    e->prof_flops.push_back(flops);
+    HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot], st));
+  }
+  SDRM_LAUNCH(e, (k_sample_persist<Cfg4>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, P);
+  HIP_TRY(e, hipGetLastError());
+  if (rec) HIP_TRY(e, hipEventRecord(e->prof_ev[2 * slot + 1], st));
+  s.i_next -= steps;
+  return SDRM_OK;
+}
+}  // namespace
 
 int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   if (!e) return SDRM_ERR_ARG;
@@ -2302,6 +2385,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   e->bwd_begun = false;
   // Train steps may run between sdrm_sample_steps calls (bench.py interleaves them): the sampler reads its own snapshot of
   // the net (sdrm_sample_begin), so they change nothing of this call.
+  if (count > 0 && s.i_next >= 1 && sample_persist_fits(e, s)) return launch_sample_persist(e, s, count, st);
   const NetView nv = snapshot_view(e);
   if (e->n_chains > 1 && !e->chains_pending) {       // fork: the other chains start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
@@ -2375,6 +2459,13 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
   if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
   if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
+  if (e->xabort_host && *e->xabort_host != 0u) {   // a hand-shake of the persistent sampler (or of a split train step) timed out
+    *e->xabort_host = 0u;
+    e->tune.smp_persist = 0; e->tune.split = 0; e->xgeoF = e->xgeoC = 0;
+    e->smp.active = false;
+    return fail(e, SDRM_ERR_HIP, "a launch that synchronises work-groups through an XCD's L2 (csrc/sample_persist.h, csrc/rows48.h) timed out: "
+                                 "the sampling call's result is invalid; those paths are switched off for this handle");
+  }
   if (e->smp.skinny)   // the persistent kernel wrote dense [n,L] rows in original order
     HIP_TRY(e, hipMemcpyAsync(out, e->X, (size_t)e->smp.n * e->L * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   else
