@@ -1032,6 +1032,13 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 
 // Row chains for a sampling call of n rows.  Measured (tools/chain_sweep.py): worthwhile once every chain
 // still has a few hundred rows.
+// Round 5 re-measured them (tools/_gen/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls):
+// two chains win from ~2700 rows on - 2715 rows 30.4 -> 27.3, 4096 rows 40.3 -> 36.1, 5429 rows 48.8 -> 44.4 (three chains: 42.6),
+// 8192 rows 67.3 -> 59.5 - and lose below (1358 rows 20.1 -> 22.9); round 1 had measured +7 % at 5429 rows, when the per-layer
+// launches were a third longer.  Inside the bench's walk (one step per call, chains joined at every train step) two chains are
+// worth +1.6 % of the headline, three and four lose.  NOT taken by default: with two concurrent streams a launch's HIP-event /
+// rocprofv3 duration includes the time it shares the chip with the other chain's launch, so per-kernel figures (bench.py's
+// `roofline`, the kernel stats under profiles/) stop meaning what they say; SDRM_CHAINS=2 / sdrm_debug_set_chains(e, 2) turn them on.
 int chains_for(const Tuning& t, int n) {
   if (t.chains >= 1) return t.chains > 4 ? 4 : t.chains;
   (void)n;

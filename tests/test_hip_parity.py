@@ -379,6 +379,38 @@ def test_narrow_net_steps_are_reproducible(engine_cls, dims):
     assert rel_l2(a, d) <= TOL and np.allclose(la, ld, rtol=1e-4)
 
 
+@pytest.mark.parametrize("path", ["row48", "row48x2", "row48x4"])
+@pytest.mark.parametrize("dims", [(340, 340, 78, 1, 700), (136, 136, 12, 2, 333), (200, 200, 9, 0, 40)])
+def test_row_group_steps_are_reproducible(engine_cls, dims, path):
+    """The 48-row row-owned step and its column-split forms (csrc/rows48.h): four fused PHILOX train steps run twice - and from a
+    shifted, odd-aligned x0 - leave the same bits in the parameters (with several work-groups per row group every one stages the same
+    tile from the same counters, owns fixed columns and writes a fixed loss partial: nothing depends on who arrives first), and agree
+    with the per-layer path to fp32 summation order."""
+    import torch
+    L, W, T, H, B = dims
+    init = synth.flatten_params(synth.init_params(L, W, T, H, seed=1), H)
+    x0 = torch.from_numpy(synth.synth_latents(B, L, seed=0)).cuda()
+
+    def run(tile, off=0):
+        e = engine_cls(L, W, T, H, B).debug_set(tile=tile)
+        e.set_params(init)
+        big = torch.zeros(B * L + off + 8, device="cuda")
+        big[off:off + B * L] = x0.reshape(-1)
+        xv = big[off:off + B * L].view(B, L)
+        losses = [float(e.train_step(xv, 1e-3, seed=5, step=k).cpu()) for k in range(4)]
+        p = e.get_params().cpu().numpy().copy()
+        e.close()
+        return p, losses
+
+    a, la = run(path)
+    b, lb = run(path)
+    c, lc = run(path, off=1)
+    d, ld = run(-1)
+    assert np.array_equal(a, b) and la == lb
+    assert np.array_equal(a, c) and la == lc
+    assert rel_l2(a, d) <= TOL and np.allclose(la, ld, rtol=1e-4)
+
+
 @pytest.mark.parametrize("path", [-1] + ROW_PATHS)
 @pytest.mark.parametrize("dims", [(340, 340, 78, 1, 160), (41, 40, 93, 5, 50), (24, 24, 9, 2, 7), (130, 130, 12, 2, 77)])
 def test_philox_mode_train(engine_cls, dims, path):

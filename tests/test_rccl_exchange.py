@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("buckets", [1, 2])
-@pytest.mark.parametrize("dims", [(340, 340, 78, 1, 1024), (40, 40, 93, 5, 107), (96, 72, 10, 0, 33)])
+@pytest.mark.parametrize("dims", [(340, 340, 78, 1, 1024), (40, 40, 93, 5, 107), (96, 72, 10, 0, 33),
+                                  # the shard sizes of the 8192 batch that take the 48-row row-owned step (csrc/rows48.h): 2048 users
+                                  # (4 GPUs) with two work-groups per row group, 4096 users (2 GPUs) with one
+                                  (340, 340, 78, 1, 2048), (340, 340, 78, 1, 4096)])
 def test_one_rank_rccl_step_equals_train_step(engine_cls, dims, buckets):
     """sdrm_train_step_sharded over a 1-rank RCCL communicator == sdrm_train_step, bit for bit, over three steps
     (loss, gradient, parameters, Adam moments), in both exchange forms: one all-reduce of the gradient after the backward
