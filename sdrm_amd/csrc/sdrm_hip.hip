@@ -725,11 +725,14 @@ bool use_rowchain(const sdrm_engine* e, int B) {
 //      a second round's worth then shares the matrix pipes: no faster than the per-layer path);
 //   2 / 4 (column-split groups, exchanged through one XCD's L2): batches of at most 2048 / 1024 users, whose groups x parts fit the
 //      chip's 256 CUs - every work-group of such a launch must be resident at once; by size only 2, for 1281 .. 2048 users.
+// the abort word of the XCD-local launches lives in host-mapped memory the GPU writes: read it as volatile
+inline unsigned xabort_read(const sdrm_engine* e) { return e->xabort_host ? *(volatile const unsigned*)e->xabort_host : 0u; }
+
 int rows48_grid(int groups, int parts) { return parts == 1 ? groups : 8 * parts * ((groups + 7) / 8); }
 int rows48_parts(const sdrm_engine* e, int B) {
   if (!e->W0f || e->tune.rows48 <= 0 || e->tune.force_cfg >= 0 || e->tune.rowchain >= 2) return 0;
   const int G = (B + R48_USERS - 1) / R48_USERS;
-  const bool can_split = e->xcd_ok && e->tune.split > 0 && e->xabort_host && *e->xabort_host == 0u;
+  const bool can_split = e->xcd_ok && e->tune.split > 0 && e->xabort_host && xabort_read(e) == 0u;
   if (can_split && e->tune.split >= 2) {
     const int parts = e->tune.split >= 4 ? 4 : 2;
     if (rows48_grid(G, parts) <= 256) return parts;
@@ -762,8 +765,8 @@ int split_sync(sdrm_engine* e, bool chain, int groups, int parts, int phases, hi
 
 // a timed-out hand-shake of an earlier column-split launch (csrc/rows48.h): reported by the next call, the path switched off
 int split_status(sdrm_engine* e) {
-  if (!e->xabort_host || *e->xabort_host == 0u) return SDRM_OK;
-  *e->xabort_host = 0u;   // reported once; the counters start over should the path ever be switched on again
+  if (xabort_read(e) == 0u) return SDRM_OK;
+  *(volatile unsigned*)e->xabort_host = 0u;   // reported once; the counters start over should the path ever be switched on again
   e->xgeoF = e->xgeoC = 0;
   e->tune.split = 0;
   e->fwd_done = false;
@@ -2319,7 +2322,7 @@ namespace {
 // CUs, the doubled CU sets every phase - 16.0 against 16.4 (19.9 one step per call), n = 1024: 18.8 against 17.7: not taken there
 constexpr int SMP_PERSIST_MAX_ROWS = 352;
 bool sample_persist_fits(const sdrm_engine* e, const SampleState& s) {
-  if (e->tune.smp_persist <= 0 || !e->xcd_ok || !e->xcntS || !e->xabort_host || *e->xabort_host != 0u) return false;
+  if (e->tune.smp_persist <= 0 || !e->xcd_ok || !e->xcntS || !e->xabort_host || xabort_read(e) != 0u) return false;
   if (s.multires || s.mode != SDRM_RNG_PHILOX || e->LP != e->WP || e->n_chains != 1) return false;
   if (e->tune.force_cfg >= 0 && e->tune.force_cfg != 4) return false;
   if (e->tune.fuse_rev == 0) return false;   // (a caller who asked for the stand-alone reverse update gets the per-layer path)
@@ -2466,8 +2469,8 @@ int sdrm_sample_end(sdrm_engine* e, float* out, void* stream) {
   if (!e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: no sampling call in progress");
   if (e->smp.i_next >= 1) return fail(e, SDRM_ERR_STATE, "sdrm_sample_end: reverse steps still pending");
   if (int jr = join_chains(e, (hipStream_t)stream)) return jr;
-  if (e->xabort_host && *e->xabort_host != 0u) {   // a hand-shake of the persistent sampler (or of a split train step) timed out
-    *e->xabort_host = 0u;
+  if (xabort_read(e) != 0u) {   // a hand-shake of the persistent sampler (or of a split train step) timed out
+    *(volatile unsigned*)e->xabort_host = 0u;
     e->tune.smp_persist = 0; e->tune.split = 0; e->xgeoF = e->xgeoC = 0;
     e->smp.active = false;
     return fail(e, SDRM_ERR_HIP, "a launch that synchronises work-groups through an XCD's L2 (csrc/sample_persist.h, csrc/rows48.h) timed out: "
