@@ -16,7 +16,8 @@ SHAPES = [  # (variant, M, N, K, label)    variant 0: A[M,K]*B[N,K]^T   1: A[M,K
     (0, 24576, 352, 352, "train fwd hid B=8192"),
     (1, 24576, 352, 352, "train dgrad   B=8192"),
     (2, 352, 352, 24576, "train wgrad   B=8192 (no split)"),
-    (0, 5504, 352, 352, "sample fwd    n=5429"),
+    (0, 5440, 352, 352, "sample fwd    n=5429"),   # the step's padded extent (85 row tiles of 64: 510 work-groups, ONE round); 5504 rows - what
+                                                   # rounds 1-4 timed here - is 516 work-groups, a second round (profiles/r05_tile_rows_cliff.txt)
     (0, 3072, 352, 352, "3072 rows (8-GPU train shard)"),
     (1, 3072, 352, 352, "3072 rows dgrad"),
     (0, 6144, 352, 352, "6144 rows (4-GPU train shard)"),
