@@ -122,6 +122,7 @@ struct GemmArgs {
   float* revX; float* revU; int rev_ldx, rev_s0, rev_n, rev_L, rev_step;
   float rev_c1, rev_sqrt_alpha, rev_sqrt_beta, rev_nd;
   uint32_t rev_seed_lo, rev_seed_hi, rev_call_id; int64_t rev_row0;
+  const int* rev_rowid;   // multi-resolution sampling: slot -> original row (the Philox key is rev_row0 + that row); null: the slot itself
   // EPI_BIAS_ROWTAB: `bias` is the table [T+1][ldtab]; stacked row r (< 3 * trow_B) belongs to user r mod trow_B, whose timestep
   // is trow[user]; pad rows use t = 0
   const int* trow; int trow_B, ldtab;
@@ -412,7 +413,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bid, cons
           if (p.rev_step > 1000000) {
 #endif
             const int slot = p.rev_s0 + rbase + (MF == 32 ? 8 * kq + h : kq);   // rowoff(kq * RQ + h)
-            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + slot), (uint32_t)(col >> 2),
+            const int rkey = (p.rev_rowid != nullptr && slot < p.rev_n) ? p.rev_rowid[slot] : slot;   // (multi-resolution: slots are sorted by start step)
+            const U4 w = philox4x32_10((uint32_t)(p.rev_row0 + rkey), (uint32_t)(col >> 2),
                                        PURPOSE_SAMPLE_STEP | ((uint32_t)p.rev_step << 8), p.rev_call_id, p.rev_seed_lo, p.rev_seed_hi);
             box_muller(w.x, w.y, n[0], n[1]);
             box_muller(w.z, w.w, n[2], n[3]);

@@ -2422,7 +2422,9 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       if (rc) return rc;
       float c1, sqrt_alpha, sqrt_beta;
       reverse_coeffs(e, i, c1, sqrt_alpha, sqrt_beta);
-      const bool fused = !s.multires && s.mode == SDRM_RNG_PHILOX && (e->tune.fuse_rev == 2 || (e->tune.fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
+      // (round 5: multi-resolution steps too - their active prefix is a launch like any other, the epilogue keys Philox by the slot's
+      // original row; EXPLICIT randoms keep the stand-alone kernel)
+      const bool fused = s.mode == SDRM_RNG_PHILOX && (e->tune.fuse_rev == 2 || (e->tune.fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
       {
         GemmArgs a{};
         a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = nv.boc;
@@ -2434,7 +2436,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
           a.revX = e->X; a.revU = e->Us; a.rev_ldx = e->LP; a.rev_s0 = s0; a.rev_n = s1; a.rev_L = L; a.rev_step = i;
           a.rev_c1 = c1; a.rev_sqrt_alpha = sqrt_alpha; a.rev_sqrt_beta = sqrt_beta; a.rev_nd = s.nd;
           a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
-          a.rev_row0 = s.row0;
+          a.rev_row0 = s.row0; a.rev_rowid = s.multires ? e->rowid_dev : nullptr;
           HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
                                                           e->LP, e->WP, sc, pr, cfg)));
           continue;

@@ -169,9 +169,8 @@ def test_sampling_headline_philox(engine_cls, sample_case, multires, tile, fused
     """The bench's own sampling mode at its own size: on-device Philox, replayed through the oracle with
     oracle/philox_ref.py (start steps bit-exact).  `fused` = sdrm_debug_set_fused_reverse: the reverse update as its own
     kernel (0), fused into the out-layer GEMM epilogue by the size rule (1) or always (2: on the 64x64 tile this is the
-    32-wide-MFMA branch of EPI_TANH_REV).  Multi-resolution never fuses, so it runs once per tile."""
-    if multires and fused != 1:
-        pytest.skip("multi-resolution sampling always uses the stand-alone reverse update")
+    32-wide-MFMA branch of EPI_TANH_REV).  Multi-resolution calls fuse by the same rules since round 5 (their active prefix is a
+    launch like any other; the epilogue keys Philox by the slot's original row)."""
     c = sample_case["philox"]
     e = engine_cls(L, W, T, H, N_SAMPLE).debug_set(tile=tile, fused_reverse=fused)
     e.set_params(synth.flatten_params(sample_case["init"], H))

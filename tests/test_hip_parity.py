@@ -529,8 +529,6 @@ def test_philox_mode_sampling(engine_cls, multires, sampler_path, tile, fused):
     from oracle import sdrm_oracle as orc
     if sampler_path and (tile != -1 or fused != 1):
         pytest.skip("the persistent narrow-net sampler has no tile / fusion choice")
-    if multires and fused != 1:
-        pytest.skip("multi-resolution sampling always uses the stand-alone reverse update")
     L, W, T, H, n = 37, 40, 12, 2, 19
     seed, call_id, nd, row0 = 99, 5, 0.9, 300
     init = synth.init_params(L, W, T, H, seed=8)
