@@ -61,6 +61,11 @@ int sdrm_debug_set_rows48(sdrm_engine* e, int mode);
  * call on the handle as SDRM_ERR_HIP and switches the path off for the handle. */
 int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode);
 int sdrm_debug_rows48_split_available(const sdrm_engine* e);
+/* The shared-tile form of the 48-row kernels (csrc/rows48.h; nets whose padded width is 4 q + 2 column tiles of 16 - 352 is 22 -, one
+ * work-group per row group): the four waves own q tiles each and the waves of a pair split the K-steps of one more, instead of
+ * multiplying two tiles of zeros in the last wave: 1 (default) on, 0 the plain form; also env SDRM_ROWS48_SHARE.  The same sums in
+ * another order for the shared tiles' columns (two partial sums over alternate K-steps). */
+int sdrm_debug_set_rows48_share(sdrm_engine* e, int on);
 /* Reverse-sampling steps without kernel boundaries between the layers (csrc/sample_persist.h: one launch per sdrm_sample_steps call
  * runs its `count` steps - every layer on the 32x32 tile, the reverse update in the out layer's epilogue - with the column tiles of
  * a row tile synchronised through ONE XCD's L2): full-resolution PHILOX sampling of a net with L == W; 0 never, 1 (default) for at

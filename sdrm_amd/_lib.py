@@ -98,6 +98,7 @@ SIGNATURES = {
     "sdrm_debug_rows48_split_available": (c_int, [c_void_p]),
     "sdrm_debug_split_skew": (c_int, [c_void_p, C.c_uint32]),
     "sdrm_debug_set_sample_persist": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_set_rows48_share": (c_int, [c_void_p, c_int]),
     "sdrm_debug_rowchain_available": (c_int, [c_void_p]),
     "sdrm_debug_set_wgrad_strips": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_dgrad_rows": (c_int, [c_void_p, c_int]),

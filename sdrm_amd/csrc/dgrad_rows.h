@@ -53,12 +53,16 @@ struct DgradRowsArgs {
 // MODE (rowchain.h): RC_NEXT_LIGHT - the G pieces fetch the compact fragments of the layer's last K-step (one float per lane at
 // k = 16 ks + lane group: `goff` then holds those offsets); RC_LIGHT - this is that K-step: one MFMA per tile.
 // GAUX: cache policy of the G fragment loads (bufres.h; BUF_SC1 where another work-group of the launch wrote G)
-template <int CT, int PH, int NA, int NB, int PRE0, int NPRE, int MODE = RC_PLAIN, int GAUX = 0>
+// [C0, C1): the tiles of the wave's CT this K-step multiplies; its NB B-fragment loads are for the tiles [L0, L0 + NB) (the shared-tile
+// form of rows48.h: a wave multiplies one tile of its window on alternate K-steps only)
+template <int CT, int PH, int NA, int NB, int PRE0, int NPRE, int MODE = RC_PLAIN, int GAUX = 0, int C0 = 0, int C1 = CT, int L0 = 0>
 __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc gr, uint32_t gnext,
                                          const uint32_t (&goff)[3], brsrc wr_, uint32_t wnext, uint32_t lane16, f32x4 (&pq)[3 * CT],
                                          brsrc pr, const uint32_t (&poff)[3]) {
   constexpr int NE = MODE == RC_LIGHT ? 1 : 4;
-  constexpr int NSLOT = 3 * NE * CT, NPIECE = NB + NA + NPRE;
+  constexpr int NTL = C1 - C0;
+  constexpr int NSLOT = 3 * NE * NTL, NPIECE = NB + NA + NPRE;
+  static_assert(0 <= C0 && C0 < C1 && C1 <= CT && L0 >= 0 && L0 + NB <= CT, "tile ranges");
   // the pieces go to the FRONT of the K-step, one per DR_PIECE_STRIDE MFMAs (behind an MFMA a load's issue is free)
   constexpr int STRIDE = NPIECE > 0 ? (NSLOT / NPIECE >= DR_PIECE_STRIDE ? DR_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1)) : NSLOT;
   static_assert(NPIECE <= NSLOT, "not enough MFMA slots for the pipeline pieces");
@@ -69,10 +73,10 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
 #pragma unroll
   for (int e = 0; e < NE; ++e)
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+  for (int ct = C0; ct < C1; ++ct)
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
-    const int s = (e * CT + ct) * 3 + rt;
+    const int s = (e * NTL + (ct - C0)) * 3 + rt;
     // swapped operands: the tile comes out transposed.  Written as asm with the accumulator tied in place: through the builtin
     // the register allocator renames accumulators in the last K-step of the loop body and copies them back at its top
     // (~250 v_accvgpr_mov per trip).  The price: the compiler's hazard recogniser does not see an MFMA here: rc_acc_begin /
@@ -84,9 +88,9 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
       const int p = s / STRIDE;
       if (p < NB) {
         if (!(DR_DIAG & 1)) {
-          uint32_t so = wnext + (p / 4) * 4096;   // opaque at this slot: pins the load here
+          uint32_t so = wnext + ((L0 + p) / 4) * 4096;   // opaque at this slot: pins the load here
           asm volatile("" : "+s"(so));
-          bl[p] = bload4(wr_, lane16 + (p % 4) * 1024, so);
+          bl[L0 + p] = bload4(wr_, lane16 + ((L0 + p) % 4) * 1024, so);
         }
       } else if (p < NB + NA) {
         if (!(DR_DIAG & 2)) {
@@ -106,11 +110,16 @@ __device__ __forceinline__ void dr_kstep(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], 
   }
 }
 
+// SH (the shared-tile form): 0 every K-step multiplies all CT tiles; 1 (the lower wave of a pair) the odd K-steps leave out the
+// window's LAST tile; 2 (the upper wave) the even K-steps leave out its FIRST tile
+__host__ __device__ constexpr int dr_c0(int SH, int K) { return (SH == 2 && (K & 1) == 0) ? 1 : 0; }
+__host__ __device__ constexpr int dr_c1(int SH, int K, int CT) { return (SH == 1 && (K & 1) == 1) ? CT - 1 : CT; }
+
 // the last PEEL K-steps, straight-line: K-step KS - PEEL + J has phase J & 3 (KS - PEEL is a multiple of four), fetches what is
 // still to come, and takes its share of the 3 * CT pre-activation quads - spread over all of them: in the last two K-steps alone
 // they are a 35 MB burst chip-wide, more than HBM delivers in that time
 // LIGHT: K-step KS - 1 is the compact one (its G fragments, fetched by K-step KS - 3, come from `goffl`)
-template <int CT, int KS, int PEEL, bool LIGHT, int J, int NCT = 2 * CT, int GAUX = 0>
+template <int CT, int KS, int PEEL, bool LIGHT, int J, int NCT = 2 * CT, int GAUX = 0, int SH = 0>
 __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f32x4 (&B)[2][CT], brsrc Gw, const uint32_t (&goff)[3],
                                         const uint32_t (&goffl)[3], brsrc Wf, uint32_t lane16, f32x4 (&pq)[3 * CT], brsrc Pw,
                                         const uint32_t (&poff)[3]) {
@@ -118,12 +127,13 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
   if constexpr (J < PEEL) {
     constexpr int K = KS - PEEL + J, NQ = 3 * CT;
     constexpr int MODE = !LIGHT ? RC_PLAIN : (K == KS - 3 ? RC_NEXT_LIGHT : (K == KS - 1 ? RC_LIGHT : RC_PLAIN));
-    constexpr int NA = K + 2 < KS ? 3 : 0, NB = K + 1 < KS ? CT : 0;
+    constexpr int NA = K + 2 < KS ? 3 : 0;
+    constexpr int L0 = dr_c0(SH, K + 1), NB = K + 1 < KS ? dr_c1(SH, K + 1, CT) - L0 : 0;   // the next K-step's tiles
     constexpr int PRE0 = J * NQ / PEEL, NPRE = (J + 1) * NQ / PEEL - PRE0;
     constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;
-    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE, GAUX>(acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf,
-                                                        (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
-    dr_peel<CT, KS, PEEL, LIGHT, J + 1, NCT, GAUX>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+    dr_kstep<CT, J & 3, NA, NB, PRE0, NPRE, MODE, GAUX, dr_c0(SH, K), dr_c1(SH, K, CT), (NB > 0 ? L0 : 0)>(
+        acc, A, B, Gw, 64u * (K + 2 < KS ? K + 2 : 0), MODE == RC_NEXT_LIGHT ? goffl : goff, Wf, (K + 1 < KS ? K + 1 : 0) * WSTEP, lane16, pq, Pw, poff);
+    dr_peel<CT, KS, PEEL, LIGHT, J + 1, NCT, GAUX, SH>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   }
 }
 
@@ -132,19 +142,25 @@ __device__ __forceinline__ void dr_peel(f32x4 (&acc)[3][CT], f32x4 (&A)[4][3], f
 // by side, CT = ceil(NCT / 4) column tiles each - the last wave's tiles beyond the NCT real ones are computed and dropped).
 // SPLIT (rows48.h, several work-groups per row group): this work-group owns the column tiles [t0, t1) only and writes slope partial
 // `pidx`; GAUX: cache policy of its G loads (the other work-groups of the group wrote most of G in this launch).
-template <int CT, bool LIGHT, int ROWS = RC_ROWS, int NCT = 2 * CT, bool SPLIT = false, int GAUX = 0>
-__device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red, int t0 = 0, int t1 = NCT, int pidx = -1) {
+// SHARE (rows48.h: ROWS = 48, NCT = 4 q + 2, CT = q + 1): the waves of a pair (0, 1) / (2, 3) have windows of CT consecutive tiles
+// that overlap in one tile, multiplied by the lower wave on the even K-steps and by the upper wave on the odd ones; the upper wave
+// hands its partial sums of that tile to the lower wave through `xsh` (2 x 3 x 64 quads of LDS), which owns the tile's epilogue.
+template <int CT, bool LIGHT, int ROWS = RC_ROWS, int NCT = 2 * CT, bool SPLIT = false, int GAUX = 0, bool SHARE = false>
+__device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* red, int t0 = 0, int t1 = NCT, int pidx = -1, f32x4* xsh = nullptr) {
   constexpr int KS = NCT, NQ = 3 * CT;
   constexpr int WC = 4 / (ROWS / 48);             // waves side by side along the columns
-  constexpr bool ALLV = !SPLIT && CT * WC == NCT; // every tile of every wave is a real one
+  constexpr bool ALLV = SHARE || (!SPLIT && CT * WC == NCT); // every tile of every wave is a real one
   static_assert(ROWS == 48 || ROWS == 96, "a work-group owns the P, S, Q rows of 16 or 32 users");
-  static_assert(SPLIT || (CT * WC >= NCT && (CT - 1) * WC < NCT), "per-wave column tiles do not cover the layer");
+  static_assert(SPLIT || SHARE || (CT * WC >= NCT && (CT - 1) * WC < NCT), "per-wave column tiles do not cover the layer");
+  static_assert(!SHARE || (ROWS == 48 && !SPLIT && NCT % 4 == 2 && CT == NCT / 4 + 1), "the shared-tile form");
   static_assert(KS % 2 == 0 && KS >= 4, "K-steps are taken in fours with a tail of two or four");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
   const int li = lane & 15, lq = lane >> 4;
   const size_t grow0 = (size_t)ROWS * g;
+  const bool upper = SHARE && (wave & 1);         // the wave whose window starts with the pair's shared tile
+  const int wt0 = SHARE ? (wave >> 1) * (NCT / 2) + (upper ? NCT / 4 : 0) : t0 + CT * wc;   // the wave's first column tile
   const uint32_t lane16 = 16u * (uint32_t)lane;
 #ifdef DR_STAMPS
   unsigned long long st_[8] = {0};
@@ -159,11 +175,11 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
     const int row = 48 * wr + 16 * rt + li;
     goff[rt] = (uint32_t)((row * a.ldg + 4 * lq) * 4);
     goffl[rt] = (uint32_t)((row * a.ldg + lq) * 4);   // the compact K-step: k = 16 ks + lq
-    poff[rt] = (uint32_t)((row * a.ldp + 16 * (t0 + CT * wc) + 4 * lq) * 4);
-    ooff[rt] = (uint32_t)((row * a.ldo + 16 * (t0 + CT * wc) + 4 * lq) * 4);
+    poff[rt] = (uint32_t)((row * a.ldp + 16 * wt0 + 4 * lq) * 4);
+    ooff[rt] = (uint32_t)((row * a.ldo + 16 * wt0 + 4 * lq) * 4);
   }
   const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(ROWS * a.ldg * 4));
-  const brsrc Wf = make_brsrc(a.WfT + (size_t)(t0 + CT * wc) * 256, (uint32_t)((KS * NCT - (t0 + CT * wc)) * 1024));
+  const brsrc Wf = make_brsrc(a.WfT + (size_t)wt0 * 256, (uint32_t)((KS * NCT - wt0) * 1024));
   const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
   gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
   const float slope = *a.slope;
@@ -185,23 +201,49 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) B[0][ct] = bload4(Wf, lane16 + ct * 1024u, 0u);
 
-  rc_acc_begin<CT>(acc);
   DR_STAMP(1);
   constexpr uint32_t WSTEP = (uint32_t)NCT * 1024u;   // bytes of one K-step of the fragment-packed weights
   // main loop: four K-steps per trip (the G sets rotate with period four, the W sets with period two); the last PEEL K-steps
   // (PEEL = KS mod 4, at most ten, at least one trip left) are straight-line code and carry the pre-activation loads
   constexpr int PEEL = KS % 4 == 2 ? (KS >= 14 ? 10 : (KS >= 10 ? 6 : 2)) : (KS >= 12 ? 8 : 4);
   static_assert((KS - PEEL) % 4 == 0 && KS - PEEL >= 4, "the main loop takes whole trips of four K-steps");
-  for (uint32_t ks = 0; ks < (uint32_t)(KS - PEEL); ks += 4) {
-    dr_kstep<CT, 0, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 2), goff, Wf, (ks + 1) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 1, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 3), goff, Wf, (ks + 2) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 2, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 4), goff, Wf, (ks + 3) * WSTEP, lane16, pq, Pw, poff);
-    dr_kstep<CT, 3, 3, CT, 0, 0, RC_PLAIN, GAUX>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
+  // (rc_acc_begin / rc_acc_settle INSIDE each instantiation of the loop: where two of them meet - the shared-tile form - the
+  // register allocator may reconcile the accumulators' registers with copies at the branch's entry and exit, and those copies must
+  // sit outside the guards, away from the asm MFMAs: tests/test_isa_lint.py found `v_accvgpr_mov a48, a4` one wait state in front
+  // of the first MFMA of a branch - wrong, run-to-run different gradients - when the guards stood around the branch)
+  auto kloop = [&](auto sh_tag) {
+    constexpr int SH = decltype(sh_tag)::value;
+    constexpr int E0 = dr_c0(SH, 0), E1 = dr_c1(SH, 0, CT), O0 = dr_c0(SH, 1), O1 = dr_c1(SH, 1, CT);   // tiles of the even / odd K-steps
+    rc_acc_begin<CT>(acc);
+    for (uint32_t ks = 0; ks < (uint32_t)(KS - PEEL); ks += 4) {
+      dr_kstep<CT, 0, 3, O1 - O0, 0, 0, RC_PLAIN, GAUX, E0, E1, O0>(acc, A, B, Gw, 64u * (ks + 2), goff, Wf, (ks + 1) * WSTEP, lane16, pq, Pw, poff);
+      dr_kstep<CT, 1, 3, E1 - E0, 0, 0, RC_PLAIN, GAUX, O0, O1, E0>(acc, A, B, Gw, 64u * (ks + 3), goff, Wf, (ks + 2) * WSTEP, lane16, pq, Pw, poff);
+      dr_kstep<CT, 2, 3, O1 - O0, 0, 0, RC_PLAIN, GAUX, E0, E1, O0>(acc, A, B, Gw, 64u * (ks + 4), goff, Wf, (ks + 3) * WSTEP, lane16, pq, Pw, poff);
+      dr_kstep<CT, 3, 3, E1 - E0, 0, 0, RC_PLAIN, GAUX, O0, O1, E0>(acc, A, B, Gw, 64u * (ks + 5), goff, Wf, (ks + 4) * WSTEP, lane16, pq, Pw, poff);
+    }
+    DR_STAMP(2);
+    dr_peel<CT, KS, PEEL, LIGHT, 0, NCT, GAUX, SH>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
+    rc_acc_settle<CT>(acc);
+  };
+  if constexpr (SHARE) {
+    if (upper) kloop(std::integral_constant<int, 2>{});
+    else kloop(std::integral_constant<int, 1>{});
+  } else {
+    kloop(std::integral_constant<int, 0>{});
   }
-  DR_STAMP(2);
-  dr_peel<CT, KS, PEEL, LIGHT, 0, NCT, GAUX>(acc, A, B, Gw, goff, goffl, Wf, lane16, pq, Pw, poff);
   DR_STAMP(3);
-  rc_acc_settle<CT>(acc);
+  if constexpr (SHARE) {
+    // the pair's shared tile: the upper wave's half of the sum goes to the lower wave (same tile, same lane layout in both)
+    if (upper) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) xsh[((wave >> 1) * 3 + rt) * 64 + lane] = acc[rt][0];
+    }
+    __syncthreads();
+    if (!upper) {
+#pragma unroll
+      for (int rt = 0; rt < 3; ++rt) acc[rt][CT - 1] += xsh[((wave >> 1) * 3 + rt) * 64 + lane];
+    }
+  }
   // epilogue: PReLU' (slope at pre <= 0, as the reference's autograd), the slope-gradient partial sum, 16-byte stores
   float part4[4] = {0.f, 0.f, 0.f, 0.f};   // four chains: one wave per SIMD, nothing else hides a dependent FMA's latency
 #pragma unroll
@@ -209,6 +251,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       if (!ALLV && t0 + CT * wc + ct >= t1) continue;   // (wave-uniform) a tile beyond the layer's / the work-group's columns: what it computed is dropped
+      if (SHARE && upper && ct == 0) continue;          // (the pair's shared tile belongs to the lower wave)
       const f32x4 p = pq[rt * CT + ct];
       f32x4 v = acc[rt][ct];
       asm("" : "+v"(v));   // one copy out of the accumulator registers, every use below reads it

@@ -73,6 +73,7 @@ struct RowChainArgs {
   unsigned long long* stamps;               // diagnostic builds only (-DRC_STAMPS): 16 s_memtime slots per work-group
   // column-split row groups only (rows48.h): the groups' hand-shake counters, and the number of row groups
   unsigned* xcnt; unsigned xbase; unsigned* xabort; int ngroups;
+  int sweep;   // rows48.h, shared-tile form: a layer's outputs leave for HBM behind the next layer's MFMAs (R48Sweep); 0: stored by its epilogue
 };
 
 #ifdef RC_STAMPS

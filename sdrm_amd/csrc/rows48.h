@@ -41,6 +41,12 @@
 #include "dgrad_rows.h"
 #include "rowchain.h"
 
+// diagnostic builds only (-DR48_DIAG=mask, timing: results are wrong): bit0 drops the epilogues' pre-activation stores, bit1 their
+// activation stores, bit2 the staging's U stores
+#ifndef R48_DIAG
+#define R48_DIAG 0
+#endif
+
 namespace sdrm {
 
 constexpr int R48_USERS = 16;
@@ -108,16 +114,129 @@ __device__ __forceinline__ f32x4 r48_load_l2(const float* p) {   // 16 bytes as 
   return v;
 }
 
+// One K-step over a WINDOW of a wave's column tiles (the shared-tile form of k_rows48_fwd, below): MFMAs for the tiles [C0, C1) of
+// the window of NW, and in their shadows the next K-step's B fragments for the tiles [L0, L1) (raw buffer wave-loads of 1 KiB) and
+// its A fragments (3 ds_read_b128).  rc_kstep (rowchain.h) with tile ranges instead of a tile count and without the tile stream:
+// the same slot discipline (one basic block, every piece's offset opaque at its slot), the same MODEs of the compact last K-step.
+// The sweep that stores a layer's outputs BEHIND the next layer's MFMAs (shared-tile form): a layer's epilogue leaves its
+// activations in the LDS tile (the next layer's input anyway) and its pre-activations in a second LDS image of the same shape;
+// each K-step of the next layer then moves ONE 4 KB chunk of either to HBM - two ds_read_b128, two 16-byte buffer stores a few
+// MFMAs later - instead of both going out in one burst that the first weight fragment behind it has to wait for (vmcnt counts loads
+// and stores in order; measured: the two bursts of a layer cost the B = 4096 forward 9.4 of its 99 us).  Chunk c = the 16-row x
+// 16-quad block (c / NCB, c % NCB), thread -> (row tid / 16, quad tid % 16): the same lane pattern at uniform offsets, stepped on
+// the scalar unit; lanes beyond the tile's last column quad (the last column block of an odd CT) and every lane of a chunk beyond
+// the tile take a byte offset outside the buffer resource - the hardware drops such stores.
+struct R48Sweep {
+  uint32_t lds0, g0, g0m;   // this lane's byte offsets in chunk 0: LDS image / HBM rows; g0m: the same, out of range where the last column block overhangs
+  uint32_t sl, sg;          // uniform byte offsets of the current chunk
+  int cb, left;             // its column block; chunks still inside the tile
+  uint32_t lwrap, gwrap;    // steps from a row block's last column block to the next row block's first
+  template <int QP, int LDA>
+  __device__ __forceinline__ void init(int tid, int ld) {
+    constexpr int NCB = (QP + 15) / 16;
+    const int r16 = tid >> 4, q16 = tid & 15;
+    lds0 = (uint32_t)((r16 * LDA + 4 * q16) * 4);
+    g0 = (uint32_t)((r16 * ld + 4 * q16) * 4);
+    g0m = (16 * (NCB - 1) + q16 < QP) ? g0 : 0x7ffffff0u;
+    sl = 0u; sg = 0u; cb = 0; left = 3 * NCB;
+    lwrap = (uint32_t)(16 * LDA * 4 - (NCB - 1) * 256);
+    gwrap = (uint32_t)(16 * ld * 4 - (NCB - 1) * 256);
+  }
+  // the current chunk's per-lane HBM offset (out of range: dropped), then on to the next chunk
+  template <int QP>
+  __device__ __forceinline__ uint32_t voff_and_next() {
+    constexpr int NCB = (QP + 15) / 16;
+    const bool lastcb = cb == NCB - 1;
+    const uint32_t vo = left > 0 ? (lastcb ? g0m : g0) : 0x7ffffff0u;
+    cb = lastcb ? 0 : cb + 1;
+    sl += lastcb ? lwrap : 256u;
+    sg += lastcb ? gwrap : 256u;
+    --left;
+    return vo;
+  }
+};
+
+template <int NW, int C0, int C1, int L0, int L1, int LDA, int MODE = RC_PLAIN, bool STREAM = false, int QP = 0>
+__device__ __forceinline__ void r48_kstep(f32x4 (&acc)[3][NW], const f32x4 (&ac)[3], const f32x4 (&bc)[NW], f32x4 (&an)[3], f32x4 (&bn)[NW],
+                                          brsrc wres, uint32_t wnext, uint32_t lane16, uint32_t anext, const float* __restrict__ Act,
+                                          R48Sweep* sw, brsrc ares, brsrc pres, uint32_t stg) {
+  constexpr int NE = MODE == RC_LIGHT ? 1 : 4;
+  constexpr int NT_ = C1 - C0, NSLOT = 3 * NE * NT_;
+  constexpr bool ST = STREAM && MODE != RC_LIGHT;
+  constexpr int P_A = MODE == RC_LIGHT ? 0 : L1 - L0, P_S = MODE == RC_LIGHT ? 0 : P_A + 3, NPIECE = P_S + (ST ? 4 : 0);
+  constexpr int STRIDE = NPIECE == 0 ? NSLOT : (NSLOT / NPIECE >= RC_PIECE_STRIDE ? RC_PIECE_STRIDE : (NSLOT / NPIECE >= 1 ? NSLOT / NPIECE : 1));
+  static_assert(0 <= C0 && C0 < C1 && C1 <= NW && 0 <= L0 && L0 <= L1 && L1 <= NW && NPIECE <= NSLOT, "tile ranges / pipeline pieces");
+  f32x4 sva = {0.f, 0.f, 0.f, 0.f}, svp = sva;
+  uint32_t sso = 0u, svo = 0u;
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+#pragma unroll
+  for (int ct = C0; ct < C1; ++ct)
+#pragma unroll
+  for (int rt = 0; rt < 3; ++rt) {
+    const int s = (e * NT_ + (ct - C0)) * 3 + rt;
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc[rt][ct]) : "v"(bc[ct][e]), "v"(ac[rt][e]));
+    if (s % STRIDE == 0 && s / STRIDE < NPIECE) {
+      const int p = s / STRIDE;
+      if (p < P_A) {
+        const int tl = L0 + p;                          // tile of the window
+        uint32_t so = wnext + (tl / 4) * 4096;          // opaque at this slot: pins the load here
+        asm volatile("" : "+s"(so));
+        bn[tl] = bload4(wres, lane16 + (tl % 4) * 1024, so);
+      } else if (p < P_S) {
+        uint32_t ao = anext;
+        asm volatile("" : "+v"(ao));
+        if (MODE == RC_NEXT_LIGHT) an[p - P_A][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * R48_USERS * LDA * 4);
+        else an[p - P_A] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + ao + (p - P_A) * R48_USERS * LDA * 4);
+      } else if constexpr (ST) {
+        // the sweep: chunk reads (activations out of the tile, pre-activations out of the image `stg` bytes behind it), then the stores
+        const int k = p - P_S;
+        if (k == 0) {
+          uint32_t lo = sw->lds0 + sw->sl;
+          asm volatile("" : "+v"(lo));
+          sva = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + lo);
+        } else if (k == 1) {
+          uint32_t lo = sw->lds0 + sw->sl + stg;
+          asm volatile("" : "+v"(lo));
+          svp = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Act) + lo);
+          sso = sw->sg;
+          svo = sw->template voff_and_next<QP>();
+        } else if (k == 2) {
+          asm volatile("" : "+s"(sso));
+          bstore4<true>(ares, svo, sso, sva);    // (nobody reads the activations before the weight gradients: non-temporal)
+        } else {
+          asm volatile("" : "+s"(sso));
+          bstore4<false>(pres, svo, sso, svp);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // LIGHT: the weight copies' last K-step is compact (a.light; the host picks the instantiation).  Arguments: rowchain.h's.
 // G: work-groups per row group (see the head of this file); grid: G = 1 one work-group per group; G > 1: 8 * G * ceil(groups / 8)
 // work-groups, block b = XCD x = b & 7, slot b >> 3 = (group x + 8 * (slot / G), part slot % G).
-template <int CT, bool LIGHT = false, int G = 1>
+// SHARE (G == 1, NCT = 4 q + 2 column tiles - NP = 352: 22): no wave multiplies tiles beyond the layer.  Wave w owns q tiles of
+// its own and HALF of one more: the two waves of a pair (0, 1) / (2, 3) have windows of q + 1 consecutive tiles that overlap in one
+// tile, which the lower wave multiplies on the even K-steps and the upper wave on the odd ones (B fragments are fetched only for
+// the K-steps a wave multiplies); behind the K loop the upper wave hands its partial sums of that tile (3 accumulator quads) to the
+// lower wave through LDS, which owns the tile's epilogue.  5.5 tiles per wave and K-step instead of 6: the 8 % of the MFMAs that the
+// plain form spends on two tiles of zeros.
+template <int CT, bool LIGHT = false, int G = 1, bool SHARE = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a) {
   typedef Rows48Cfg<CT, G> C;
-  constexpr int NP = C::NP, NCT = C::NCT, NCG = C::NCG, CW = C::CW, KS = C::KS, QP = C::QP, LDA = C::LDA, NQ = C::NQ, RT = 3;
-  constexpr bool ALLV = 4 * CW == NCG && NCG * G == NCT;   // every tile of every wave is a real one
+  constexpr int NP = C::NP, NCT = C::NCT, NCG = C::NCG, KS = C::KS, QP = C::QP, LDA = C::LDA, NQ = C::NQ, RT = 3;
+  constexpr int Q4 = NCT / 4;
+  constexpr int CW = SHARE ? Q4 + 1 : C::CW;               // tiles a wave holds accumulators for (SHARE: its window)
+  constexpr bool ALLV = SHARE || (4 * CW == NCG && NCG * G == NCT);   // every tile of every wave is a real one
   static_assert(KS % 2 == 0, "K-steps are taken in pairs");
-  __shared__ __attribute__((aligned(16))) float Act[R48_ROWS * LDA];
+  static_assert(!SHARE || (G == 1 && NCT % 4 == 2), "the shared-tile form: one work-group per row group, 4 q + 2 column tiles");
+  __shared__ f32x4 xsh[SHARE ? 2 * 3 * 64 : 1];            // SHARE: the upper waves' partial sums of the pairs' shared tiles
+  // (SHARE: a second image of the tile's shape behind it takes a layer's pre-activations until the next layer's K-steps have
+  // moved them to HBM - R48Sweep)
+  __shared__ __attribute__((aligned(16))) float Act[(SHARE ? 2 : 1) * R48_ROWS * LDA];
+  constexpr uint32_t STG = (uint32_t)(R48_ROWS * LDA * 4);
   __shared__ int trow[R48_USERS];
   __shared__ double red[16];
   __shared__ int go;
@@ -239,9 +358,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       *reinterpret_cast<f32x4*>(Act + (2 * R48_USERS + su) * LDA + c) = fQ;
       // the layer-0 operand of the weight gradients, from the same registers (nobody reads it before them: non-temporal)
       const uint32_t uo = (uint32_t)((su * a.K0 + c) * 4), up = (uint32_t)(R48_USERS * a.K0 * 4);
-      bstore4<true>(ures, uo, 0u, fP);
-      bstore4<true>(ures, uo + up, 0u, fS);
-      bstore4<true>(ures, uo + 2 * up, 0u, fQ);
+      if (!(R48_DIAG & 4)) {
+        bstore4<true>(ures, uo, 0u, fP);
+        bstore4<true>(ures, uo + up, 0u, fS);
+        bstore4<true>(ures, uo + 2 * up, 0u, fQ);
+      }
     }
   }
   __syncthreads();
@@ -254,7 +375,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
   const uint32_t aoffl = (uint32_t)((li * LDA + lq) * 4);        // ... of the compact K-step's fragment (k = 16 ks + lq)
   const uint32_t lane16 = 16u * (uint32_t)lane;
   const int myrow = li;                            // + 16 rt: the lane's row of the tile; its user is u0 + li
-  const int wt0 = t0 + CW * wc;                    // the wave's first column tile
+  const bool upper = SHARE && (wc & 1);            // SHARE: the wave whose window STARTS with the pair's shared tile
+  const int wt0 = SHARE ? (wc >> 1) * (2 * Q4 + 1) + (upper ? Q4 : 0) : t0 + CW * wc;   // the wave's first column tile
   const int mycol = 16 * wt0 + 4 * lq;             // + 16 ct: the first of its four columns
   float* __restrict__ otile = Act + myrow * LDA + mycol;
   f32x4 acc[RT][CW];
@@ -273,7 +395,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       const float* bsrc = layer == 0 ? a.B0tab + (size_t)trow[myrow] * a.ldtab : (last ? a.bo : a.bh);
 #pragma unroll
       for (int ct = 0; ct < CW; ++ct) {
-        const bool tv = ALLV || wt0 + ct < t1;
+        const bool tv = SHARE ? !(upper && ct == 0) : (ALLV || wt0 + ct < t1);   // (SHARE: the upper wave's partial sums start at zero)
         const float4 bv = tv ? *reinterpret_cast<const float4*>(bsrc + mycol + 16 * ct) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt][ct] = f32x4{bv.x, bv.y, bv.z, bv.w};
@@ -294,7 +416,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) a0[rt] = *reinterpret_cast<const f32x4*>(abase + rt * R48_USERS * LDA);
     constexpr uint32_t WS = NCT * 1024;
-    rc_acc_begin<CW>(acc);
+    if constexpr (!SHARE) rc_acc_begin<CW>(acc);
+    if constexpr (SHARE) {
+      // even K-steps: the lower wave multiplies its whole window [0, CW), the upper wave [1, CW); odd K-steps the other way round
+      // ([0, CW - 1) / [0, CW)); each K-step fetches the B fragments of the tiles the NEXT one multiplies
+      // the previous layer's outputs leave for HBM behind this layer's MFMAs, one chunk per K-step (layer 0: nothing to move, the
+      // sweep starts with no chunks left and every store of it is dropped)
+      R48Sweep swp;
+      swp.template init<QP, LDA>(tid, a.ldp);
+      if (layer == 0 || !a.sweep) swp.left = 0;
+      const size_t lrow = (size_t)(layer > 0 ? layer - 1 : 0) * a.pre_stride + grow0 * a.ldp;
+      const brsrc ares = make_brsrc(a.act + lrow, layer > 0 ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
+      const brsrc pres = make_brsrc(a.pre + lrow, layer > 0 ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
+      auto kloop = [&](auto up_tag) {
+        constexpr bool UP = decltype(up_tag)::value;
+        constexpr int E0 = UP ? 1 : 0, E1 = CW, O0 = 0, O1 = UP ? CW : CW - 1;   // tile ranges of the even / the odd K-steps
+        rc_acc_begin<CW>(acc);   // (the guards inside each branch: dgrad_rows.h, dr_layer)
+#pragma unroll 1
+        for (uint32_t ks = 0; ks < (uint32_t)KS - 2; ks += 2) {
+          r48_kstep<CW, E0, E1, O0, O1, LDA, RC_PLAIN, true, QP>(acc, a0, b0, a1, b1, Wf, (ks + 1) * WS, lane16, aoff + 64u * (ks + 1), Act, &swp, ares, pres, STG);
+          r48_kstep<CW, O0, O1, E0, E1, LDA, RC_PLAIN, true, QP>(acc, a1, b1, a0, b0, Wf, (ks + 2) * WS, lane16, aoff + 64u * (ks + 2), Act, &swp, ares, pres, STG);
+        }
+        if constexpr (LIGHT) {
+          r48_kstep<CW, E0, E1, O0, O1, LDA, RC_NEXT_LIGHT, true, QP>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoffl + 64u * (KS - 1), Act, &swp, ares, pres, STG);
+          r48_kstep<CW, O0, O1, O0, O0, LDA, RC_LIGHT>(acc, a1, b1, a0, b0, Wf, 0u, lane16, aoff, Act, &swp, ares, pres, STG);
+        } else {
+          r48_kstep<CW, E0, E1, O0, O1, LDA, RC_PLAIN, true, QP>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoff + 64u * (KS - 1), Act, &swp, ares, pres, STG);
+          r48_kstep<CW, O0, O1, O0, O0, LDA, RC_PLAIN, true, QP>(acc, a1, b1, a0, b0, Wf, (KS - 2) * WS, lane16, aoff + 64u * (KS - 2), Act, &swp, ares, pres, STG);   // (A fragments past the end: a harmless re-read)
+        }
+        rc_acc_settle<CW>(acc);
+      };
+      if (upper) kloop(std::true_type{});
+      else kloop(std::false_type{});
+    } else {
 #pragma unroll 1   // (a narrow net's few trips would be unrolled into the layer loop: code size for nothing)
     for (uint32_t ks = 0; ks < (uint32_t)KS - 2; ks += 2) {
       rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a0, b0, a1, b1, Wf, (ks + 1) * WS, lane16, aoff + 64u * (ks + 1), Act, nores, sw);
@@ -308,12 +462,25 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a0, b0, a1, b1, Wf, (KS - 1) * WS, lane16, aoff + 64u * (KS - 1), Act, nores, sw);
       rc_kstep<CW, LDA, 0, false, false, RC_PLAIN, R48_USERS>(acc, a1, b1, a0, b0, Wf, (KS - 2) * WS, lane16, aoff + 64u * (KS - 2), Act, nores, sw);   // past the end: a harmless re-read
     }
-    rc_acc_settle<CW>(acc);
+    }
+    if constexpr (!SHARE) rc_acc_settle<CW>(acc);
+    if constexpr (SHARE) {
+      // the pair's shared tile: the upper wave's half of the sum goes to the lower wave (same tile, same lane layout in both)
+      if (upper) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xsh[((wc >> 1) * 3 + rt) * 64 + lane] = acc[rt][0];
+      }
+      __syncthreads();   // (for a hidden layer also: every wave is done reading the tile)
+      if (!upper) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt][CW - 1] += xsh[((wc >> 1) * 3 + rt) * 64 + lane];
+      }
+    }
     if (last) break;
 
     // in-place epilogue: every wave is done reading the tile; then the pre-activations go to HBM as they are (read next by the
     // dgrads), their PReLU into the tile - the next layer's input - and to HBM (act[layer]: what the weight gradients read)
-    __syncthreads();
+    if constexpr (!SHARE) __syncthreads();
     {
       const float slope = layer == 0 ? *a.slope0 : *a.slopeh;
       gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
@@ -325,10 +492,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
 #pragma unroll
         for (int ct = 0; ct < CW; ++ct) {
           if (!ALLV && wt0 + ct >= t1) continue;   // (wave-uniform) a tile beyond the layer's / the work-group's columns
+          if (SHARE && upper && ct == 0) continue;  // (the pair's shared tile belongs to the lower wave)
           const f32x4 v = acc[rt][ct];
           const float4 h = make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
-          gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
-          gstore4(aw + ct * 64, pbase + rt * prt, h);
+          if (SHARE && a.sweep) {
+            // both stay in LDS: the next layer's K-steps move them to HBM (R48Sweep)
+            *reinterpret_cast<float4*>(otile + (R48_ROWS + rt * R48_USERS) * LDA + 16 * ct) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            if (!(R48_DIAG & 1)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+            if (!(R48_DIAG & 2)) gstore4(aw + ct * 64, pbase + rt * prt, h);
+          }
           *reinterpret_cast<float4*>(otile + rt * R48_USERS * LDA + 16 * ct) = h;
         }
     }
@@ -363,6 +536,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
 #pragma unroll
   for (int ct = 0; ct < CW; ++ct) {
     if (!ALLV && wt0 + ct >= t1) continue;
+    if (SHARE && upper && ct == 0) continue;
     const int col = mycol + 16 * ct;
     float fD = 0.f, fC = 0.f, fR = 0.f, fR2 = 0.f;
     float P[4], S[4], Q[4];
@@ -404,10 +578,14 @@ struct DgradChain48Args {
 // G > 1 (column-split row groups, see the head of this file): every work-group of a group computes the group's seeds itself (its
 // own copy of dY: the same values at the same addresses), owns 1 / G of every layer's output columns, and the group meets between
 // two layers - layer l + 1 reduces over ALL columns of layer l's output, which it then reads from the XCD's L2 (sc1 loads).
-template <int CT, bool LIGHT = false, int G = 1>
+// SHARE: the shared-tile form (see k_rows48_fwd): G == 1, 4 q + 2 column tiles.
+template <int CT, bool LIGHT = false, int G = 1, bool SHARE = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradChain48Args ca) {
   typedef Rows48Cfg<CT, G> C;
-  constexpr int CW = C::CW, NCT = C::NCT, NCG = C::NCG, NQ = C::NQ;
+  constexpr int NCT = C::NCT, NCG = C::NCG, NQ = C::NQ;
+  constexpr int CW = SHARE ? NCT / 4 + 1 : C::CW;
+  static_assert(!SHARE || (G == 1 && NCT % 4 == 2), "the shared-tile form: one work-group per row group, 4 q + 2 column tiles");
+  __shared__ f32x4 xsh[SHARE ? 2 * 3 * 64 : 1];
   __shared__ float red[4];
   __shared__ double shs[4], tot[4];
   __shared__ int go;
@@ -515,7 +693,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_dgrad_chain(const DgradC
       }
     } else {
       __syncthreads();   // the work-group's own stores of the previous stage have landed (and `red` is free again)
-      dr_layer<CW, LIGHT, R48_ROWS, NCT>(c.layer[l], g, red);
+      dr_layer<CW, LIGHT, R48_ROWS, NCT, false, 0, SHARE>(c.layer[l], g, red, 0, NCT, -1, xsh);
     }
   }
 }

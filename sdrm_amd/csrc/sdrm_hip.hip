@@ -68,6 +68,8 @@ struct Tuning {
   int rows48 = 1;                // SDRM_ROWS48: the row-owned train step on 48-row work-groups (csrc/rows48.h: 16 users' P, S, Q rows; the
                                  // same nets as rowchain) for batches that do not fill the chip with 96-row work-groups: 0 never, 1 when
                                  // the batch's 16-user groups fill most of one round of the chip (see use_rows48), 2 whenever the net allows
+  int rows48_share = 7;          // (bit 0: the forward, bit 1: the dgrad chain, bit 2: the forward's deferred-store sweep) SDRM_ROWS48_SHARE: the shared-tile form of the 48-row kernels (csrc/rows48.h: widths of 4 q + 2 column tiles - 352 is
+                                 // 22 - no wave multiplies tiles beyond the layer; the waves of a pair split one tile's K-steps): 1 on, 0 the plain form
   int smp_persist = 1;           // SDRM_SAMPLE_PERSIST: reverse steps without kernel boundaries between the layers (csrc/sample_persist.h; full
                                  // resolution, PHILOX, L == W, one row chain): 0 never, 1 for at most SMP_PERSIST_MAX_ROWS (352) rows, 2 whenever it fits
   int split = 1;                 // SDRM_ROWS48_SPLIT: column-split row groups of that step (G work-groups of one XCD share a 48-row group and
@@ -776,6 +778,13 @@ int split_status(sdrm_engine* e) {
 
 template <int CT, int PARTS>
 int launch_rows48_forward_ctp(sdrm_engine* e, const RowChainArgs& a, int grid, hipStream_t st) {
+  if constexpr (PARTS == 1 && CT % 2 == 1) {   // 2 CT = 4 q + 2 column tiles: the shared-tile form
+    if (e->tune.rows48_share & 1) {
+      if (a.light) SDRM_LAUNCH(e, (k_rows48_fwd<CT, true, 1, true>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+      else SDRM_LAUNCH(e, (k_rows48_fwd<CT, false, 1, true>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+      return SDRM_OK;
+    }
+  }
   if (a.light) SDRM_LAUNCH(e, (k_rows48_fwd<CT, true, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
   else SDRM_LAUNCH(e, (k_rows48_fwd<CT, false, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
   return SDRM_OK;
@@ -807,6 +816,13 @@ int launch_rows48_forward_ct(sdrm_engine* e, RowChainArgs& a, int G, int parts, 
 
 template <int CT, int PARTS>
 int launch_rows48_chain_ctp(sdrm_engine* e, const DgradChain48Args& a, int grid, hipStream_t st) {
+  if constexpr (PARTS == 1 && CT % 2 == 1) {   // 2 CT = 4 q + 2 column tiles: the shared-tile form
+    if (e->tune.rows48_share & 2) {
+      if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, true, 1, true>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+      else SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, false, 1, true>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
+      return SDRM_OK;
+    }
+  }
   if (rc_light_klast(e->W, e->WP) >= 0) SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, true, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
   else SDRM_LAUNCH(e, (k_rows48_dgrad_chain<CT, false, PARTS>), dim3((unsigned)grid), dim3(NTHREADS), 0, st, a);
   return SDRM_OK;
@@ -883,6 +899,7 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.pre = e->pre; a.pre_stride = (size_t)e->MPmax * e->WP; a.ldp = e->WP; a.Y = e->Y; a.ldy = e->LP;
   a.act = e->act;
   a.loss_part = e->loss_part;
+  a.sweep = (e->tune.rows48_share & 4) ? 1 : 0;
   if (rows48_parts_ > 0) {
     switch (e->WP / 32) {
       case 4: return launch_rows48_forward_ct<4>(e, a, G, rows48_parts_, st);
@@ -1138,6 +1155,12 @@ int sdrm_debug_set_rows48_split(sdrm_engine* e, int mode) {
 
 int sdrm_debug_rows48_split_available(const sdrm_engine* e) { return e && e->W0f && e->xcd_ok ? 1 : 0; }
 
+int sdrm_debug_set_rows48_share(sdrm_engine* e, int on) {
+  if (!e) return SDRM_ERR_ARG;
+  e->tune.rows48_share = on == 1 ? 7 : (on == 2 ? 5 : (on == 3 ? 2 : 0));   // 1: forward (with its sweep) and chain, 2: the forward only, 3: the chain only
+  return SDRM_OK;
+}
+
 int sdrm_debug_set_sample_persist(sdrm_engine* e, int mode) {
   if (!e) return SDRM_ERR_ARG;
   if (e->smp.active) return fail(e, SDRM_ERR_STATE, "sdrm_debug_set_sample_persist: inside a sampling call");
@@ -1275,6 +1298,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_ROWS48")) e->tune.rows48 = std::atoi(env);
   if (const char* env = std::getenv("SDRM_ROWS48_SPLIT")) e->tune.split = std::atoi(env);
   if (const char* env = std::getenv("SDRM_SAMPLE_PERSIST")) e->tune.smp_persist = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_ROWS48_SHARE")) e->tune.rows48_share = std::atoi(env);
   if (const char* env = std::getenv("SDRM_WGRAD_STRIPS")) e->tune.strips = std::atoi(env);
   if (const char* env = std::getenv("SDRM_DGRAD_ROWS")) e->tune.dgrad_rows = std::atoi(env);
   e->L = L; e->W = W; e->T = T; e->H = H; e->max_rows = max_rows; e->device = device_id;

@@ -103,13 +103,15 @@ class Engine:
         return t.contiguous()
 
     def debug_set(self, tile=None, skinny=None, fused_reverse=None, chains=None, nt32_rows=None, nt32_rows_train=None,
-                  gradient_buckets=None, rowchain=None, wgrad_strips=None, dgrad_rows=None, rows48=None, rows48_split=None, sample_persist=None):
+                  gradient_buckets=None, rowchain=None, wgrad_strips=None, dgrad_rows=None, rows48=None, rows48_split=None, sample_persist=None, rows48_share=None):
         """Test / tuning hooks of THIS engine (include/sdrm_hip_debug.h): force a GEMM tile shape (-1 = automatic),
         switch the narrow-net kernels, the fused reverse update, the sampler row chains, the 32x32-tile row thresholds,
         the number of gradient all-reduces of the sharded step (1 or 2), the row-owned train forward (0 never, 1 by
         size, 2 whenever the net allows), the strip-owned weight gradients and the row-owned input gradients behind it."""
         if rowchain is not None:
             self._check(self.lib.sdrm_debug_set_rowchain(self._h, int(rowchain)), "sdrm_debug_set_rowchain")
+        if rows48_share is not None:   # the shared-tile form of the 48-row kernels (1 on, 0 the plain form)
+            self._check(self.lib.sdrm_debug_set_rows48_share(self._h, int(rows48_share)), "sdrm_debug_set_rows48_share")
         if sample_persist is not None:   # reverse steps in one launch (csrc/sample_persist.h): 0 never, 1 by size, 2 whenever it fits
             self._check(self.lib.sdrm_debug_set_sample_persist(self._h, int(sample_persist)), "sdrm_debug_set_sample_persist")
         if rows48_split is not None:   # column-split row groups of that step: 0 never, 1 by size, 2 / 4 work-groups per group

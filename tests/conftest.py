@@ -47,14 +47,16 @@ def engine_cls():
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope (or no block -> XCD mapping)")
                 kw = dict(kw, tile=None, rowchain=0, rows48=2, rows48_split=int(kw["tile"][-1]), wgrad_strips=True, dgrad_rows=1)
-            if kw.get("tile") in ("row48", "row48-tiles"):
+            if kw.get("tile") in ("row48", "row48-tiles", "row48-plain"):
                 # the row-owned step on 48-row work-groups (csrc/rows48.h) forced on: "row48" with its dgrad chain and the strip-owned
-                # weight gradients behind it, "row48-tiles" the same forward with k_loss_seed + tile dgrads + batched tile weight gradients
+                # weight gradients behind it, "row48-tiles" the same forward with k_loss_seed + tile dgrads + batched tile weight gradients,
+                # "row48-plain": "row48" without the shared-tile form of its kernels
                 if not self.rowchain_available:
                     self.close()
                     pytest.skip("shape outside the row-owned forward's envelope")
                 mode = kw["tile"]
-                kw = dict(kw, tile=None, rowchain=0, rows48=2, rows48_split=0, wgrad_strips=mode == "row48", dgrad_rows=1 if mode == "row48" else 0)
+                kw = dict(kw, tile=None, rowchain=0, rows48=2, rows48_split=0, wgrad_strips=mode != "row48-tiles", dgrad_rows=0 if mode == "row48-tiles" else 1,
+                          rows48_share=mode != "row48-plain")
             if kw.get("tile") in ("row", "row-layers", "row-tiles"):
                 if not self.rowchain_available:
                     self.close()

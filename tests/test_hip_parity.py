@@ -41,7 +41,7 @@ def sampler_path(request):
 
 TILES = [-1, 0, 4]   # automatic; forced 64x64x16 (32-wide MFMA); forced 32x32x32 (16-wide MFMA): every step-level test
                      # below runs on each, so a size-threshold retune cannot change which kernels the suite covers
-ROW_PATHS = ["row", "row-layers", "row-tiles", "row48", "row48-tiles", "row48x2", "row48x4"]   # the row-owned forwards: 96-row work-groups (csrc/rowchain.h) with each
+ROW_PATHS = ["row", "row-layers", "row-tiles", "row48", "row48-tiles", "row48-plain", "row48x2", "row48x4"]   # the row-owned forwards: 96-row work-groups (csrc/rowchain.h) with each
                      # backward behind them, 48-row work-groups (csrc/rows48.h) with their own chain + strips, or with the tile backward
 TRAIN_PATHS = TILES + ROW_PATHS   # train-step tests also run through the row-owned forwards (grouped row orders)
 

@@ -80,7 +80,7 @@ def _wait_states(x):
 VALU_OK_IN_LOOP = ("v_mfma",)
 
 
-@pytest.mark.parametrize("ct", [4, 11])
+@pytest.mark.parametrize("ct", [4, 5, 7, 11])
 def test_row_owned_kernels_isa(ct):
     light = "true" if ct == 11 else "false"   # the compact last K-step (340 = 21 * 16 + 4) on the headline width, plain on the other
     asm = _compile(f"template __global__ void sdrm::k_dgrad_chain<{ct}, {light}>(const sdrm::DgradChainArgs);\n"
@@ -91,13 +91,19 @@ def test_row_owned_kernels_isa(ct):
                    f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}>(const sdrm::DgradChain48Args);\n"
                    # ... and with two work-groups per row group (column-split, the form the size rule takes for 1281 .. 2048 users)
                    f"template __global__ void sdrm::k_rows48_fwd<{ct}, {light}, 2>(const sdrm::RowChainArgs);\n"
-                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}, 2>(const sdrm::DgradChain48Args);\n")
+                   f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}, 2>(const sdrm::DgradChain48Args);\n"
+                   # ... and the shared-tile form (4 q + 2 column tiles: the waves of a pair split one tile's K-steps)
+                   + (f"template __global__ void sdrm::k_rows48_fwd<{ct}, {light}, 1, true>(const sdrm::RowChainArgs);\n"
+                      f"template __global__ void sdrm::k_rows48_dgrad_chain<{ct}, {light}, 1, true>(const sdrm::DgradChain48Args);\n" if ct % 2 else ""))
     ks = _kernels(asm)
     names = {"chain": [n for n in ks if "k_dgrad_chain" in n and "rows48" not in n], "rows": [n for n in ks if "k_dgrad_rows" in n],
-             "fwd": [n for n in ks if "k_row_fwd" in n], "fwd48": [n for n in ks if "k_rows48_fwd" in n and "ELi2E" not in n],
-             "chain48": [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi2E" not in n],
+             "fwd": [n for n in ks if "k_row_fwd" in n], "fwd48": [n for n in ks if "k_rows48_fwd" in n and "ELi2E" not in n and "ELi1ELb1E" not in n],
+             "chain48": [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi2E" not in n and "ELi1ELb1E" not in n],
              "fwd48x2": [n for n in ks if "k_rows48_fwd" in n and "ELi2E" in n],
              "chain48x2": [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi2E" in n]}
+    if ct % 2:
+        names["fwd48s"] = [n for n in ks if "k_rows48_fwd" in n and "ELi1ELb1E" in n]
+        names["chain48s"] = [n for n in ks if "k_rows48_dgrad_chain" in n and "ELi1ELb1E" in n]
     assert all(len(v) == 1 for v in names.values()), names
     for kind, (name,) in names.items():
         ins = ks[name]
@@ -109,7 +115,7 @@ def test_row_owned_kernels_isa(ct):
         # (the layer loops have barriers, a K loop has none)
         kloops = [(a, b) for a, b in inner if sum(1 for x in ins[a:b] if x.startswith("v_mfma")) >= 24 and "s_barrier" not in ins[a:b]]
         # (a K loop of a single trip is straight-line code: the narrowest nets of the dgrad kernels)
-        assert kloops or (not kind.startswith("fwd") and ct <= 5), kind
+        assert kloops or (not kind.startswith("fwd") and ct <= 7), kind   # (up to 14 K-steps the dgrads' main loop is a single trip of four)
         for a, b in kloops:
             body = ins[a:b]
             assert not [x for x in body if x.startswith("v_accvgpr")], (kind, "accumulator copies inside a K loop")
