@@ -47,7 +47,7 @@ int sdrm_debug_set_skinny(sdrm_engine* e, int on);
 int sdrm_debug_set_rowchain(sdrm_engine* e, int mode);
 /* The row-owned train step on 48-row work-groups (csrc/rows48.h: the P, S, Q rows of 16 users per work-group through staging,
  * every layer and the loss sums, then through the loss seeds and every layer's input gradient; the nets of the row-owned forward):
- * 0 never, 1 (default) when the batch's 16-user groups fill most of one round of the chip (176..256 groups: 2801..4096 users) and
+ * 0 never, 1 (default) when the batch's 16-user groups fill most of one round of the chip (160..256 groups: 2545..4096 users) and
  * the 96-row kernels do not take the batch, 2 whenever the net allows (tests); also env SDRM_ROWS48.  sdrm_debug_set_rowchain(e, 2)
  * and a forced tile take precedence.  The stacked rows of such a step are grouped by 16 users (elementwise.h).  Refused between
  * sdrm_train_backward_begin and _finish; drops a pending train forward. */

@@ -723,7 +723,7 @@ bool use_rowchain(const sdrm_engine* e, int B) {
 
 // The same step on 48-row work-groups (csrc/rows48.h), for batches the 96-row kernels would leave CUs idle with.  Returns the
 // work-groups per 16-user row group, 0: not this path.
-//   1: the groups of the batch fill most of ONE round of the chip (176..256 groups: 2801..4096 users; two work-groups fit a CU, but
+//   1: the groups of the batch fill most of ONE round of the chip (160..256 groups: 2545..4096 users; two work-groups fit a CU, but
 //      a second round's worth then shares the matrix pipes: no faster than the per-layer path);
 //   2 / 4 (column-split groups, exchanged through one XCD's L2): batches of at most 2048 / 1024 users, whose groups x parts fit the
 //      chip's 256 CUs - every work-group of such a launch must be resident at once; by size only 2, for 1281 .. 2048 users.
@@ -745,7 +745,7 @@ int rows48_parts(const sdrm_engine* e, int B) {
   // users on - B = 2048: 174 against 201 us, B = 1536: 164 against 170 - four per group do not: B = 1024: 140 against 131, the
   // redundant staging and the two hand-shakes per kernel cost what the five launches saved)
   if (can_split && e->tune.split == 1 && G > 80 && rows48_grid(G, 2) <= 256) return 2;       // 1281 .. 2048 users
-  return (G >= 176 && G <= 256) ? 1 : 0;
+  return (G >= 160 && G <= 256) ? 1 : 0;   // (2545 .. 4096 users; measured: 2560 users 231 against 235 us, 2688 231 / 241, 2432 228 / 224)
 }
 
 // the hand-shake counters of a column-split launch: they count on from launch to launch while the geometry stays the same
