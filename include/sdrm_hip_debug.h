@@ -86,7 +86,8 @@ int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on);
  * gradient, operands straight from global memory, PReLU' and the slope partial sums on 16-byte quads) behind the row-owned
  * forward: 1 (default) the loss value, the gradient seeds and every layer's dgrad in ONE launch (k_dgrad_chain: rows never meet, a
  * work-group runs down the chain on its own), 2 k_loss_seed + one k_dgrad_rows launch per layer, 0 k_loss_seed + the 64x64-tile
- * launches; also env SDRM_DGRAD_ROWS.  Takes effect with the next backward. */
+ * launches; also env SDRM_DGRAD_ROWS.  Drops a pending train forward (a row-owned forward stores no pre-activations when these
+ * kernels follow: they read the activations). */
 int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int mode);
 /* 1 when this engine's shape qualifies for the row-owned forward (its fragment-packed weight copies exist). */
 int sdrm_debug_rowchain_available(const sdrm_engine* e);

@@ -34,6 +34,9 @@ struct DgradRowsArgs {
   const float* G; int ldg;      // incoming gradient [MP][ldg], columns [0, NP) are the reduction axis
   const float* WfT;             // fragment-packed [NP/16][NP/16][64][4]: element (n = in, k = out), wfrag_index(n, k, NP / 16)
   const float* pre; int ldp;    // pre-activations of the layer below [MP][ldp]
+  const float* act;             // ... its activations prelu(pre) in the same layout, and whether to read THEM (`from_act`, with a positive
+  int from_act;                 // slope): PReLU'(v) = (prelu(v) > 0 ? 1 : slope) and sum dh min(v, 0) = (sum dh min(prelu(v), 0)) / slope -
+                                // the forward then need not store the pre-activations at all (rowchain.h: skip_pre)
   const float* slope;           // its PReLU slope
   float* out; int ldo;          // [MP][ldo]
   float* slope_part;            // [gridDim.x]
@@ -180,9 +183,10 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   }
   const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(ROWS * a.ldg * 4));
   const brsrc Wf = make_brsrc(a.WfT + (size_t)wt0 * 256, (uint32_t)((KS * NCT - wt0) * 1024));
-  const brsrc Pw = make_brsrc(a.pre + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
-  gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
   const float slope = *a.slope;
+  const bool ua = a.from_act && slope > 0.f;   // (uniform) the activations stand in for the pre-activations
+  const brsrc Pw = make_brsrc((ua ? a.act : a.pre) + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
+  gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
 
   f32x4 acc[3][CT];
   f32x4 A[4][3];    // G fragments of K-step k live in A[k & 3] (fetched two K-steps ahead)
@@ -269,7 +273,10 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
   if (lane == 0) red[wave] = part;
   __syncthreads();
-  if (tid == 0) a.slope_part[pidx >= 0 ? pidx : g] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid == 0) {
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    a.slope_part[pidx >= 0 ? pidx : g] = ua ? tot / slope : tot;   // (min(prelu(v), 0) = slope * min(v, 0))
+  }
 #ifdef DR_STAMPS
   DR_STAMP(4);
   if (tid == 0 && a.stamps) {

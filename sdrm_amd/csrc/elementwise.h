@@ -797,6 +797,21 @@ __global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L,
   }
 }
 
+// ... of a layer whose pre-activations the forward did not store (rowchain.h: skip_pre): v = prelu(v) where that is positive,
+// prelu(v) / slope below (the slope is positive whenever the forward skipped the store; else `pre` holds them)
+__global__ __launch_bounds__(256) void k_unpad_pre(const float* pre, const float* act, const float* slope, int B, int W, int WP, int grouped, float* dst) {
+  const float sl = *slope;
+  const bool from_act = act != nullptr && sl > 0.f;
+  const size_t total = (size_t)3 * B * W;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / W; const int c = (int)(i - r * W);
+    const int pass = (int)(r / B), user = (int)(r - (size_t)pass * B);
+    const size_t at = stacked_row(grouped, pass, user, B) * WP + c;
+    if (from_act) { const float h = act[at]; dst[i] = h > 0.f ? h : h / sl; }
+    else dst[i] = pre[at];
+  }
+}
+
 // Test hook (sdrm_debug_philox_draws): the generator's output exactly as the staging kernels consume it - one Philox call per
 // (row, column quad): four normals (two Box-Muller pairs) and the low bits of the four words (bit b of word j = keep bit of
 // pass b for column j in the train step).

@@ -73,6 +73,9 @@ struct RowChainArgs {
   unsigned long long* stamps;               // diagnostic builds only (-DRC_STAMPS): 16 s_memtime slots per work-group
   // column-split row groups only (rows48.h): the groups' hand-shake counters, and the number of row groups
   unsigned* xcnt; unsigned xbase; unsigned* xabort; int ngroups;
+  int skip_pre;   // the backward of this step reads a layer's ACTIVATIONS where it used to read pre-activations (dgrad_rows.h: PReLU' and
+                  // the slope gradient follow from prelu(v) when the slope is positive), so the forward need not store pre[k]:
+                  // 35 MB per layer at B = 8192 that every epilogue burst out at once; a slope <= 0 keeps the stores (decided on the device)
   int sweep;   // rows48.h, shared-tile form: a layer's outputs leave for HBM behind the next layer's MFMAs (R48Sweep); 0: stored by its epilogue
 };
 
@@ -482,12 +485,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
       gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);
       const uint32_t prt = (uint32_t)(RC_USERS * a.ldp * 4);
+      if (!(a.skip_pre && slope > 0.f)) {   // (uniform) somebody will read the pre-activations themselves
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            const f32x4 v = acc[rt][ct];
+            if (!(RC_DIAG & 8)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+          }
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
           const f32x4 v = acc[rt][ct];
-          if (!(RC_DIAG & 8)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
           *reinterpret_cast<float4*>(otile + rt * RC_USERS * LDA + 16 * ct) =
               make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
         }

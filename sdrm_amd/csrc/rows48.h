@@ -427,7 +427,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       if (layer == 0 || !a.sweep) swp.left = 0;
       const size_t lrow = (size_t)(layer > 0 ? layer - 1 : 0) * a.pre_stride + grow0 * a.ldp;
       const brsrc ares = make_brsrc(a.act + lrow, layer > 0 ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
-      const brsrc pres = make_brsrc(a.pre + lrow, layer > 0 ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
+      const bool prev_keep_pre = !(a.skip_pre && (layer <= 1 ? *a.slope0 : *a.slopeh) > 0.f);   // (of the layer whose outputs are swept now)
+      const brsrc pres = make_brsrc(a.pre + lrow, layer > 0 && prev_keep_pre ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
       auto kloop = [&](auto up_tag) {
         constexpr bool UP = decltype(up_tag)::value;
         constexpr int E0 = UP ? 1 : 0, E1 = CW, O0 = 0, O1 = UP ? CW : CW - 1;   // tile ranges of the even / the odd K-steps
@@ -483,6 +484,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
     if constexpr (!SHARE) __syncthreads();
     {
       const float slope = layer == 0 ? *a.slope0 : *a.slopeh;
+      const bool keep_pre = !(a.skip_pre && slope > 0.f);   // (uniform; rowchain.h: skip_pre)
       gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       gchar* aw = uniform_gptr(a.act + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);
@@ -497,9 +499,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
           const float4 h = make_float4(prelu_any(v[0], slope), prelu_any(v[1], slope), prelu_any(v[2], slope), prelu_any(v[3], slope));
           if (SHARE && a.sweep) {
             // both stay in LDS: the next layer's K-steps move them to HBM (R48Sweep)
-            *reinterpret_cast<float4*>(otile + (R48_ROWS + rt * R48_USERS) * LDA + 16 * ct) = make_float4(v[0], v[1], v[2], v[3]);
+            if (keep_pre) *reinterpret_cast<float4*>(otile + (R48_ROWS + rt * R48_USERS) * LDA + 16 * ct) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            if (!(R48_DIAG & 1)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
+            if (keep_pre && !(R48_DIAG & 1)) gstore4(pw + ct * 64, pbase + rt * prt, make_float4(v[0], v[1], v[2], v[3]));
             if (!(R48_DIAG & 2)) gstore4(aw + ct * 64, pbase + rt * prt, h);
           }
           *reinterpret_cast<float4*>(otile + rt * R48_USERS * LDA + 16 * ct) = h;

@@ -97,6 +97,7 @@ struct sdrm_engine {
   bool cur_sk = false;               // ... grouped by 16 users (the narrow nets' step, csrc/skinny_step.h)
   bool cur_g16 = false;              // ... grouped by 16 users by the 48-row row-owned forward (csrc/rows48.h)
   int cur_rows = 0;                  // stacked rows the last train_forward really wrote (whole groups; cur_MP rounds them up to the tile)
+  bool cur_skip_pre = false;         // that forward was told not to store the pre-activations (the row-owned dgrads read the activations)
   int cur_parts = 1;                 // work-groups per row group of that forward (csrc/rows48.h: 1, or 2 / 4 column-split)
   // column-split row groups: hand-shake counters of the forward / of the dgrad chain [256 groups][32], never reset while the
   // launch geometry stays the same (xgeo); the abort word lives in host-visible memory (xabort_host / its device alias)
@@ -632,6 +633,12 @@ bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && 
 // 182 + 18.7 + 11.7 us); a last round that leaves more than a sixth of the CUs idle loses to the per-layer path.
 // row-owned dgrads (dgrad_rows.h): the stacked rows are whole 96-row work-groups (the grouped order of the row-owned forward),
 // reduction axis == output axis == the padded width (LP == WP: L == W)
+// will the backward of a row-owned forward of `rows` stacked rows (padded to MP) be the row-owned dgrads (dr_layer: chain or one
+// launch per layer)?  Asked by the forward too: they read activations, so it need not store pre-activations (rowchain.h: skip_pre)
+bool row_dgrads_follow(const sdrm_engine* e, bool g16, int MP) {
+  if (!e->WhfT || e->tune.dgrad_rows <= 0 || e->LP != e->WP || e->WP < 128 || e->WP > 352) return false;
+  return g16 ? e->H + 1 <= DR_MAX_LAYERS : MP % RC_ROWS == 0;
+}
 bool use_dgrad_rows(const sdrm_engine* e, int MP) {
   return e->cur_grouped && e->WhfT && e->tune.dgrad_rows > 0 && e->LP == e->WP && MP % RC_ROWS == 0 && e->WP >= 128 && e->WP <= 352;
 }
@@ -659,6 +666,8 @@ DgradRowsArgs dgrad_rows_args(const sdrm_engine* e, const float* G, const float*
                               float* partial) {
   DgradRowsArgs a{};
   a.G = G; a.ldg = e->WP; a.WfT = WfT; a.pre = pre; a.ldp = e->WP; a.slope = slope; a.out = out; a.ldo = e->WP; a.slope_part = partial;
+  // the layer's activations sit at the same place of the `act` buffer as its pre-activations in `pre`
+  a.act = e->act ? e->act + (pre - e->pre) : nullptr; a.from_act = (e->cur_act && e->cur_skip_pre && a.act) ? 1 : 0;
   return a;
 }
 
@@ -900,6 +909,11 @@ int launch_row_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   a.act = e->act;
   a.loss_part = e->loss_part;
   a.sweep = (e->tune.rows48_share & 4) ? 1 : 0;
+  {
+    const int MPg = rows48_parts_ > 0 ? round_up(G * R48_ROWS, BM) : round_up(G * RC_ROWS, BM);
+    a.skip_pre = row_dgrads_follow(e, rows48_parts_ > 0, MPg) ? 1 : 0;
+    e->cur_skip_pre = a.skip_pre != 0;
+  }
   if (rows48_parts_ > 0) {
     switch (e->WP / 32) {
       case 4: return launch_rows48_forward_ct<4>(e, a, G, rows48_parts_, st);
@@ -1184,6 +1198,7 @@ int sdrm_debug_set_wgrad_strips(sdrm_engine* e, int on) {
 
 int sdrm_debug_set_dgrad_rows(sdrm_engine* e, int on) {
   if (!e) return SDRM_ERR_ARG;
+  e->fwd_done = false;   // a pending row-owned forward chose what it stores (pre-activations or not) by the old setting
   e->tune.dgrad_rows = on < 0 ? 0 : (on > 2 ? 2 : on);
   return SDRM_OK;
 }
@@ -1528,7 +1543,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
 
-  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false; e->cur_g16 = false; e->cur_rows = MP; e->cur_parts = 1;
+  e->cur_grouped = false; e->cur_act = false; e->cur_sk = false; e->cur_g16 = false; e->cur_rows = MP; e->cur_parts = 1; e->cur_skip_pre = false;
   if (int xs = split_status(e)) return xs;
   if (skinny_net(e)) {
     // narrow net (csrc/skinny_step.h): staging, all layers and the loss partial sums of 16 users' P, S, Q rows per work-group in
@@ -2529,8 +2544,9 @@ int sdrm_get_preacts(const sdrm_engine* e, int layer, float* out, void* stream) 
   sdrm_engine* me = const_cast<sdrm_engine*>(e);
   if (!e->fwd_done) return fail(me, SDRM_ERR_STATE, "sdrm_get_preacts: no train forward yet");
   if (layer < 0 || layer > e->H) return fail(me, SDRM_ERR_ARG, "sdrm_get_preacts: layer outside [0,H]");
-  SDRM_LAUNCH(e, k_unpad_psq, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer),
-                     e->cur_B, e->W, e->WP, (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0), out);
+  const float* actl = (e->cur_act && e->cur_skip_pre && e->act) ? e->act + (size_t)layer * e->MPmax * e->WP : nullptr;
+  SDRM_LAUNCH(e, k_unpad_pre, dim3(256), dim3(256), 0, (hipStream_t)stream, (const float*)pre_buf(me, layer), actl,
+                     (const float*)slope_ptr(me, layer), e->cur_B, e->W, e->WP, (e->cur_sk || e->cur_g16) ? 2 : (e->cur_grouped ? 1 : 0), out);
   HIP_TRY(me, hipGetLastError());
   return SDRM_OK;
 }
