@@ -184,7 +184,7 @@ __device__ __forceinline__ void dr_layer(const DgradRowsArgs& a, int g, float* r
   const brsrc Gw = make_brsrc(a.G + grow0 * a.ldg, (uint32_t)(ROWS * a.ldg * 4));
   const brsrc Wf = make_brsrc(a.WfT + (size_t)wt0 * 256, (uint32_t)((KS * NCT - wt0) * 1024));
   const float slope = *a.slope;
-  const bool ua = a.from_act && slope > 0.f;   // (uniform) the activations stand in for the pre-activations
+  const bool ua = a.from_act && slope >= SLOPE_FROM_ACT_MIN;   // (uniform) the activations stand in for the pre-activations
   const brsrc Pw = make_brsrc((ua ? a.act : a.pre) + grow0 * a.ldp, (uint32_t)(ROWS * a.ldp * 4));
   gchar* Ow = uniform_gptr(a.out + grow0 * a.ldo);
 

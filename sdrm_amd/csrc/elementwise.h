@@ -28,6 +28,9 @@ __host__ __device__ inline size_t stacked_row(int grouped, int pass, int user, i
 // the backward, against ~0.5 k of MFMA + LDS work.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// A layer's activations prelu(v) stand in for its pre-activations v in the row-owned backward (rowchain.h: skip_pre) when the slope
+// is at least this: positive, and far enough from zero that slope * v neither underflows nor loses min(v, 0) to rounding
+constexpr float SLOPE_FROM_ACT_MIN = 1e-6f;
 constexpr float MU = 0.1f;          // score_matching_loss(..., mu=.1), :333
 constexpr float MU2 = 0.01f;        // mu ** 2, :196
 
@@ -801,7 +804,7 @@ __global__ __launch_bounds__(256) void k_unpad_psq(const float* Y, int B, int L,
 // prelu(v) / slope below (the slope is positive whenever the forward skipped the store; else `pre` holds them)
 __global__ __launch_bounds__(256) void k_unpad_pre(const float* pre, const float* act, const float* slope, int B, int W, int WP, int grouped, float* dst) {
   const float sl = *slope;
-  const bool from_act = act != nullptr && sl > 0.f;
+  const bool from_act = act != nullptr && sl >= SLOPE_FROM_ACT_MIN;
   const size_t total = (size_t)3 * B * W;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t r = i / W; const int c = (int)(i - r * W);

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_row_fwd(const RowChainArgs a) {
       gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);
       const uint32_t prt = (uint32_t)(RC_USERS * a.ldp * 4);
-      if (!(a.skip_pre && slope > 0.f)) {   // (uniform) somebody will read the pre-activations themselves
+      if (!(a.skip_pre && slope >= SLOPE_FROM_ACT_MIN)) {   // (uniform) somebody will read the pre-activations themselves
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll

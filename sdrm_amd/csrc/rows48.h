@@ -427,7 +427,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
       if (layer == 0 || !a.sweep) swp.left = 0;
       const size_t lrow = (size_t)(layer > 0 ? layer - 1 : 0) * a.pre_stride + grow0 * a.ldp;
       const brsrc ares = make_brsrc(a.act + lrow, layer > 0 ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
-      const bool prev_keep_pre = !(a.skip_pre && (layer <= 1 ? *a.slope0 : *a.slopeh) > 0.f);   // (of the layer whose outputs are swept now)
+      const bool prev_keep_pre = !(a.skip_pre && (layer <= 1 ? *a.slope0 : *a.slopeh) >= SLOPE_FROM_ACT_MIN);   // (of the layer whose outputs are swept now)
       const brsrc pres = make_brsrc(a.pre + lrow, layer > 0 && prev_keep_pre ? (uint32_t)(R48_ROWS * a.ldp * 4) : 0u);
       auto kloop = [&](auto up_tag) {
         constexpr bool UP = decltype(up_tag)::value;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_rows48_fwd(const RowChainArgs a
     if constexpr (!SHARE) __syncthreads();
     {
       const float slope = layer == 0 ? *a.slope0 : *a.slopeh;
-      const bool keep_pre = !(a.skip_pre && slope > 0.f);   // (uniform; rowchain.h: skip_pre)
+      const bool keep_pre = !(a.skip_pre && slope >= SLOPE_FROM_ACT_MIN);   // (uniform; rowchain.h: skip_pre)
       gchar* pw = uniform_gptr(a.pre + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       gchar* aw = uniform_gptr(a.act + (size_t)layer * a.pre_stride + grow0 * a.ldp);
       const uint32_t pbase = (uint32_t)((myrow * a.ldp + mycol) * 4);

@@ -783,3 +783,38 @@ def test_split_row_groups_time_out_instead_of_hanging(engine_cls):
     lb = float(ref.train_step(x0, 1e-3, noise=eps, t=t, keep=keep).cpu())
     assert abs(la - lb) <= 1e-5 * abs(lb) and rel_l2(e.get_params().cpu().numpy(), ref.get_params().cpu().numpy()) <= 1e-5
     e.close(); ref.close()
+
+
+@pytest.mark.parametrize("path", ["row", "row-layers", "row48", "row48-plain", "row48x2"])
+@pytest.mark.parametrize("slopes", [(0.25, 0.25), (0.0, 0.3), (0.2, 0.0), (-0.15, 0.25), (0.25, -0.3), (1e-30, 2.5), (1e-6, 3e-5)])
+def test_row_owned_steps_at_every_sign_of_the_prelu_slopes(engine_cls, slopes, path):
+    """Round 5: behind a row-owned forward the row-owned dgrads read the ACTIVATIONS - PReLU'(v) = (prelu(v) > 0 ? 1 : a)
+    and sum dh min(v, 0) = (sum dh min(prelu(v), 0)) / a - so the forward stores no pre-activations.  That holds for a positive slope a
+    only (at least 1e-6: below that a * v underflows); a slope of zero (prelu(v) = 0 wherever v <= 0: min(v, 0) is gone) or below
+    (prelu(v) > 0 on both sides) keeps the stores and
+    the old arithmetic, decided on the device layer by layer.  Every sign combination of the two slopes (`dnn.1.weight` behind layer 0,
+    `dnn.3.weight` behind the shared hidden layer; train_SDRM.py:93-95), one step, against the CPU oracle: loss, every gradient
+    tensor (incl. both slope gradients), the reconstructed pre-activations of sdrm_get_preacts."""
+    from oracle import sdrm_oracle as orc
+    L, W, T, H, B = 136, 136, 12, 2, 150
+    init = synth.init_params(L, W, T, H, seed=41)
+    init["dnn.1.weight"] = np.full((1,), slopes[0], np.float32)
+    init["dnn.3.weight"] = np.full((1,), slopes[1], np.float32)
+    x0 = synth.synth_latents(B, L, seed=42)
+    eps, t, masks = synth.synth_train_randoms(B, L, T, 0.9, seed=43)
+    e = engine_cls(L, W, T, H, B).debug_set(tile=path)
+    e.set_params(synth.flatten_params(init, H))
+    e.train_forward(x0, noise=eps, t=t, keep=masks)
+    o = orc.Oracle(L, W, T, H, init)
+    caches = []
+    o.loss_and_grads(x0, eps, t, list(masks), caches=caches)
+    branch, flips = engine_branch_masks(e, o, caches, B)     # (reads the engine's pre-activations: reconstructed where they were not stored)
+    loss_ref, grads_ref, _, _ = o.loss_and_grads(x0, eps, t, list(masks), neg_override=branch)
+    loss = float(e.train_backward().cpu())
+    assert abs(loss - float(loss_ref)) <= 1e-4 * abs(float(loss_ref))
+    g = e.get_grads().cpu().numpy()
+    for (name, got) in per_tensor(g, (L, W, T, H)):
+        ref = np.asarray(grads_ref[name], dtype=np.float32).reshape(got.shape)
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        assert float(np.abs(got - ref).max()) <= 1e-4 * scale + 1e-9, (name, slopes, path, float(np.abs(got - ref).max()) / scale)
+    e.close()
