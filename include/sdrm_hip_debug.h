@@ -98,9 +98,13 @@ int sdrm_debug_rowchain_available(const sdrm_engine* e);
  * arithmetic. */
 int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode);
 /* Row chains of a sampling call (csrc/sdrm_hip.hip: independent row ranges run on separate HIP streams so that one
- * chain's launch gaps are filled by another's kernels): -1 = by size (default), 1..4 forced; also env SDRM_CHAINS.
- * Results do not depend on it (rows are independent and randoms are keyed by row). */
+ * chain's launch gaps are filled by another's kernels): -1 = by size (default: sdrm_debug_chains), 1..4 forced; also env SDRM_CHAINS.
+ * Rows are independent and randoms are keyed by row: every chain count computes the same call; the tile and the fusion of the reverse
+ * update go by a chain's row count, so the last bits may differ between chain counts (never between two runs of one). */
 int sdrm_debug_set_chains(sdrm_engine* e, int chains);
+/* The number of row chains of the sampling call in progress (or of the last one); by size: two once the call has 2560 x 352 elements
+ * per layer (ML-1M: n >= 2560 rows).  While an event profile is recorded (sdrm_profile_begin) the chains run one after the other. */
+int sdrm_debug_chains(const sdrm_engine* e);
 
 /* Gradient all-reduces of sdrm_train_step_sharded: 1 (default) = one all-reduce of the whole flat gradient after the one-call
  * backward; 2 = the two buckets of sdrm_grad_buckets, the first overlapped with the upper layers' weight gradients on the

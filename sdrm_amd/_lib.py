@@ -90,6 +90,7 @@ SIGNATURES = {
     "sdrm_debug_set_tile": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_nt32_rows": (c_int, [c_void_p, c_int, c_int]),
     "sdrm_debug_set_chains": (c_int, [c_void_p, c_int]),
+    "sdrm_debug_chains": (c_int, [c_void_p]),
     "sdrm_debug_set_fused_reverse": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_skinny": (c_int, [c_void_p, c_int]),
     "sdrm_debug_set_rowchain": (c_int, [c_void_p, c_int]),

@@ -293,7 +293,10 @@ int pick_cfg(const Tuning& t) { return (t.force_cfg >= 0 && t.force_cfg < N_TILE
 // up to a few thousand rows and loses above (tools/shard_probe.py, sample step at 679 / 1358 / 2715 / 5429 rows:
 // 19.3 / 25.6 / 36.9 / 60.1 us against 23.5 / 31.6 / 49.9 / 54.2; train step at 3072 / 6144 / 12288 / 24576 stacked
 // rows: 156 / 235 / 375 / 683 against 170 / 235 / 363 / 629) - the 64x64 tile moves half the operand bytes per flop.
-// (64x32 and 32x64 tiles on the 16-wide MFMA were tried for the large launches: 644 / 661 us per train step against 618.)
+// (64x32 and 32x64 tiles on the 16-wide MFMA were tried for the large launches: 644 / 661 us per train step against 618; round 5 tried
+// 64x32x32, 32x64x32 and 64x64x32 on the 16-wide MFMA again where the 32x32 tile runs today - ML-100k's NT launches 350.5 / 345.6 / 378.5 us
+// per train step against 348.0, the sampler's two chains at 5429 rows 46.3 / 45.7 / 58.9 us per step against 44.0, one chain at 679
+// rows 22.1 / 21.0 / 32.7 against 16.7: profiles/r05_nt_tiles.txt.  The operand bytes per flop are not what bounds these launches.)
 int choose_cfg(const Tuning& t, int M, int nt32_rows) {
   if (t.force_cfg >= 0 && t.force_cfg < N_TILE_CFGS) return t.force_cfg;
   return M <= nt32_rows ? 4 : 0;
@@ -1064,19 +1067,19 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
   return SDRM_OK;
 }
 
-// Row chains for a sampling call of n rows.  Measured (tools/chain_sweep.py): worthwhile once every chain
-// still has a few hundred rows.
-// Round 5 re-measured them (tools/_gen/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls):
-// two chains win from ~2700 rows on - 2715 rows 30.4 -> 27.3, 4096 rows 40.3 -> 36.1, 5429 rows 48.8 -> 44.4 (three chains: 42.6),
-// 8192 rows 67.3 -> 59.5 - and lose below (1358 rows 20.1 -> 22.9); round 1 had measured +7 % at 5429 rows, when the per-layer
-// launches were a third longer.  Inside the bench's walk (one step per call, chains joined at every train step) two chains are
-// worth +1.6 % of the headline, three and four lose.  NOT taken by default: with two concurrent streams a launch's HIP-event /
-// rocprofv3 duration includes the time it shares the chip with the other chain's launch, so per-kernel figures (bench.py's
-// `roofline`, the kernel stats under profiles/) stop meaning what they say; SDRM_CHAINS=2 / sdrm_debug_set_chains(e, 2) turn them on.
-int chains_for(const Tuning& t, int n) {
+// Row chains for a sampling call of n rows (rows are independent through the whole reverse loop, so a row range can run as a chain
+// of launches on a stream of its own; the ramp and drain of one chain's launch are then filled by the other's).  Measured in round 5
+// (tools/_gen/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls): two chains win from
+// ~2700 rows on - 2715 rows 30.4 -> 27.3, 4096 rows 40.3 -> 36.1, 5429 rows 48.8 -> 44.4, 8192 rows 67.3 -> 59.5 - and lose below
+// (1358 rows 20.1 -> 22.9: a launch of half the rows no longer fills the chip).  Three chains: 42.6 at 5429 rows, worse elsewhere, and
+// worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
+// (tools/_gen/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
+// The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
+// While an event profile is recorded (sdrm_profile_begin) the chains run one after the other on the caller's stream: intervals of
+// launches that share the chip would overlap and say nothing about either kernel.
+int chains_for(const Tuning& t, int n, int WP) {
   if (t.chains >= 1) return t.chains > 4 ? 4 : t.chains;
-  (void)n;
-  return 1;
+  return (size_t)n * (size_t)WP >= (size_t)2560 * 352 ? 2 : 1;
 }
 
 int upload_schedule(sdrm_engine* e, float beta1, float beta2) {
@@ -1242,6 +1245,8 @@ int sdrm_debug_set_chains(sdrm_engine* e, int chains) {
   e->tune.chains = chains;
   return SDRM_OK;
 }
+
+int sdrm_debug_chains(const sdrm_engine* e) { return e ? e->n_chains : 0; }
 
 int sdrm_debug_set_tile(sdrm_engine* e, int cfg) {
   if (!e) return SDRM_ERR_ARG;
@@ -2269,7 +2274,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   if (int jr = join_chains(e, st)) return jr;
   const int T = e->T, L = e->L, MP = round_up(n, BM);
   e->fwd_done = false;
-  e->n_chains = chains_for(e->tune, n);
+  e->n_chains = chains_for(e->tune, n, e->WP);
   e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
   int rc = ensure_tables(e, st);
@@ -2436,7 +2441,10 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   // the net (sdrm_sample_begin), so they change nothing of this call.
   if (count > 0 && s.i_next >= 1 && sample_persist_fits(e, s)) return launch_sample_persist(e, s, count, st);
   const NetView nv = snapshot_view(e);
-  if (e->n_chains > 1 && !e->chains_pending) {       // fork: the other chains start after everything queued on st so far
+  const bool serial = e->prof_on;                    // (chains_for: an event profile wants launches that do not share the chip)
+  if (serial) {
+    if (int jr = join_chains(e, st)) return jr;
+  } else if (e->n_chains > 1 && !e->chains_pending) {   // fork: the other chains start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
     for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
     e->chains_pending = true;                        // joined lazily by the next entry point that needs the result
@@ -2447,7 +2455,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     for (int c = 0; c < e->n_chains; ++c) {
       const int s0 = c * e->chain_chunk, s1 = std::min(na, s0 + e->chain_chunk);
       if (s1 <= s0) break;
-      hipStream_t sc = c == 0 ? st : e->aux[c - 1];
+      hipStream_t sc = (c == 0 || serial) ? st : e->aux[c - 1];
       const int rows = s1 - s0, MP = round_up(rows, BM);
       const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows);
       {

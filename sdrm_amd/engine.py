@@ -140,6 +140,11 @@ class Engine:
         return self
 
     @property
+    def sampler_chains(self):
+        """Row chains of the sampling call in progress / of the last one (csrc/sdrm_hip.hip: chains_for)."""
+        return int(self.lib.sdrm_debug_chains(self._h))
+
+    @property
     def rows48_split_available(self):
         """True when column-split row groups (csrc/rows48.h) may be taken: the net qualifies and the chip maps block b to XCD b & 7."""
         return bool(self.lib.sdrm_debug_rows48_split_available(self._h))

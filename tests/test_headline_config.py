@@ -204,3 +204,44 @@ def test_sampling_interleaved_with_train_steps(engine_cls, sample_case):
     out = e.sample_end()
     assert k >= 10 and bool((out == ref).all())
     e.close()
+
+
+@pytest.mark.parametrize("multires", [False, True])
+def test_sampler_row_chains_change_no_bit(engine_cls, sample_case, multires):
+    """Sampling calls of this size run as two row chains on two streams by default (csrc/sdrm_hip.hip: chains_for): rows are independent
+    through the whole reverse loop and the generator is keyed by row, so one to four chains all reproduce the oracle's latents (the
+    tile and the fusion of the reverse update go by a chain's row count, so the bits may differ between chain counts), and the same
+    chain count gives the same bits - also when an event profile, which serialises the chains, begins and ends inside the call."""
+    c = sample_case["philox"]
+    flat = synth.flatten_params(sample_case["init"], H)
+    kw = dict(nd=ND, multires=multires, seed=c["seed"], call_id=c["call_id"], row0=c["row0"])
+    outs = {}
+    for chains in (-1, 1, 2, 3, 4):
+        e = engine_cls(L, W, T, H, N_SAMPLE).debug_set(chains=chains)
+        e.set_params(flat)
+        outs[chains] = e.sample(N_SAMPLE, **kw).cpu()
+        assert e.sampler_chains == (2 if chains == -1 else chains)
+        e.close()
+    for chains in (-1, 1, 2, 3, 4):
+        assert close(outs[chains], c["multi" if multires else "full"]), chains
+    assert bool((outs[2] == outs[-1]).all())
+    # the size rule: one chain for one rank of eight, two for one rank of two
+    for n, want in ((679, 1), (2715, 2)):
+        e = engine_cls(L, W, T, H, n)
+        e.set_params(flat)
+        e.sample(n, nd=ND, seed=1)
+        assert e.sampler_chains == want
+        e.close()
+    # an event profile that begins and ends inside the call
+    e = engine_cls(L, W, T, H, N_SAMPLE)
+    e.set_params(flat)
+    e.sample_begin(N_SAMPLE, **kw)
+    e.sample_steps(20)
+    e.profile_begin(capacity=4096)
+    e.sample_steps(25)
+    prof = e.profile_end()
+    assert prof
+    while e.sample_steps(9) > 0:
+        pass
+    assert bool((e.sample_end().cpu() == outs[-1]).all())
+    e.close()
