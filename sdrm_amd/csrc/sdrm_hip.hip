@@ -1069,11 +1069,11 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 
 // Row chains for a sampling call of n rows (rows are independent through the whole reverse loop, so a row range can run as a chain
 // of launches on a stream of its own; the ramp and drain of one chain's launch are then filled by the other's).  Measured in round 5
-// (tools/_gen/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls): two chains win from
+// (tools/ab/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls): two chains win from
 // ~2700 rows on - 2715 rows 30.4 -> 27.3, 4096 rows 40.3 -> 36.1, 5429 rows 48.8 -> 44.4, 8192 rows 67.3 -> 59.5 - and lose below
 // (1358 rows 20.1 -> 22.9: a launch of half the rows no longer fills the chip).  Three chains: 42.6 at 5429 rows, worse elsewhere, and
 // worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
-// (tools/_gen/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
+// (tools/ab/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
 // The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
 // While an event profile is recorded (sdrm_profile_begin) the chains run one after the other on the caller's stream: intervals of
 // launches that share the chip would overlap and say nothing about either kernel.
