@@ -507,6 +507,13 @@ def main():
     dt, kinds = combine_windows(window_ms, window_trains, args.steps)
 
     sampler_chains = int(getattr(eng, "sampler_chains", 1))   # (concurrent row chains of the sampling call, by size)
+    # The event passes time the sampler on ONE chain: intervals of launches that share the chip overlap (and the library would run the
+    # chains one after the other under an event profile: half-size launches that cannot fill the chip alone) - either way not a
+    # per-kernel figure.  One chain is the same kernels on full-size launches; the timed windows above ran `sampler_chains`.
+    if sampler_chains > 1 and hasattr(eng, "debug_set"):
+        while job.k % job.cycle != 0:      # to the start of a job cycle: no sampling call open
+            job.step()
+        eng.debug_set(chains=1)
     # ---- second, untimed-for-throughput pass with HIP events around every GEMM launch: at least two job cycles, so the
     # dominant class (one batched weight-gradient launch per train step) is averaged over >= 30 launches
     prof_steps = max(args.steps, 2 * n_cycle)
@@ -536,6 +543,8 @@ def main():
             prof_dom = alone[dom_name]
         eng.profile_begin(capacity=1)          # (all classes again for any later caller)
         eng.profile_end()
+    if sampler_chains > 1 and hasattr(eng, "debug_set"):
+        eng.debug_set(chains=-1)
 
     # ---- separate train-only / sample-only rates (extra information, not `value`)
     def rate(fn, reps):
@@ -546,13 +555,11 @@ def main():
         barrier()
         return reps / (time.perf_counter() - t)
 
-    while eng.sample_steps(1) != 0:   # drain a sampling call left open by the cyclic walk
-        pass
-    try:
+    if job.sampling:                      # drain a sampling call left open by the cyclic walk
+        while eng.sample_steps(1) != 0:
+            pass
         eng.sample_end()
-    except Exception:
-        pass
-    job.sampling = False
+        job.sampling = False
     train_rate = rate(lambda: trainer.train_step(x0, wl["lr"], row0=row0, step=7, seed=99, nd=wl["nd"]), 20)
     eng.sample_begin(n_local, nd=wl["nd"], seed=5, call_id=777, row0=srow0)
     sample_rate = rate(lambda: eng.sample_steps(1), 60)
@@ -594,8 +601,8 @@ def main():
                     "timing_note": "achieved / avg_launch_us: HIP events around the launches of this class only (its own pass; the three "
                                    "largest classes are each timed that way and the largest total names the dominant one); "
                                    "all_kernels: every GEMM class bracketed in one pass, each interval 3-10 us high from the neighbours' markers"
-                                   + ("; the sampler's row chains (two launches of half the rows each, concurrent in the timed windows) "
-                                      "run one after the other while events are recorded" if sampler_chains > 1 else ""),
+                                   + (f"; sampling classes: timed on one row chain (full-size launches) - the timed windows run {sampler_chains} "
+                                      "concurrent chains of half-size launches, whose intervals overlap" if sampler_chains > 1 else ""),
                     "mfma_busy_cycles_per_simd": pmc_mfma_busy(name, lib_hash),
                     "mfma_util_note": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs per launch (PMC pass); divide by avg_launch_us x "
                                       "shader clock (~2.1 GHz in kernels this short, tools/mfma_probe.hip) for the pipe utilisation",
