@@ -1965,6 +1965,9 @@ int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
 
 // the whole backward in one call: same kernels, one tail for both buckets; `fused_lr` (the single-GPU step): Adam applied by the
 // tail itself, straight from the slab sums (the flat gradient is still written: sdrm_get_grads)
+// (Round 5 measured the single-GPU tail as two concurrent halves - the hidden / output layers' jobs on an auxiliary stream beside layer 0's
+// jobs + k_tail_emb, optionally + the next step's k_emb_tables: the fork and the join cost more than the overlap gains on this runtime,
+// train step 450.7 -> 467.3 / 457.4 us at B = 8192, 72.8 -> 98.9 at B = 160, ADM 47.2 -> 66.4: profiles/r05_tail_split.txt.)
 static int train_backward_impl(sdrm_engine* e, const double* sums, float* grad, float* loss, hipStream_t st, const float* fused_lr) {
   e->bwd_begun = false;
   float* gout = grad ? grad : e->g;
