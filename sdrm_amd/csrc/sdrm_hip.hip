@@ -1075,6 +1075,10 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 // worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
 // (tools/ab/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
 // The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
+// A train step between two sampling steps joins the chains and the next sampling step forks them again (~20 us per train step in
+// bench.py's walk).  Letting them run on beside the train step - the sampler in layer buffers of its own, no join in sdrm_train_forward -
+// was built and measured: 8850 -> 8565 steps/s; a launch of one work-group per CU that finds some CUs busy with the other stream's
+// work-groups ends a whole work-group time later.
 // While an event profile is recorded (sdrm_profile_begin) the chains run one after the other on the caller's stream: intervals of
 // launches that share the chip would overlap and say nothing about either kernel.
 int chains_for(const Tuning& t, int n, int WP) {
