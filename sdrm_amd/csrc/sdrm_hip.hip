@@ -122,6 +122,8 @@ struct sdrm_engine {
                                                                // trailing columns of the train step's layer-0 operand); b0 + C0[t]
   float *sched = nullptr;  // [8][T+1]: beta alpha alphabar sqrt_ab one_minus_ab
   float *Us = nullptr;               // sampler's own layer-0 input [rows][LP] (survives train steps between sample_steps calls)
+  float *smp_pre = nullptr, *smp_Y = nullptr;   // ... and its own layer buffers / eps-net output: a train step between two sampling steps
+                                     // shares nothing with the call in progress (sdrm_train_forward: no join of the row chains)
   float *U = nullptr, *pre = nullptr, *Y = nullptr, *dY = nullptr, *dA = nullptr, *X = nullptr;
   float *slab0 = nullptr, *slabH = nullptr, *slabO = nullptr, *db0s = nullptr, *dbHs = nullptr, *dbOs = nullptr;
   float *alpha_part = nullptr;
@@ -174,6 +176,7 @@ struct sdrm_engine {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   int n_chains = 1, chain_chunk = 0;
   bool chains_pending = false;
+  bool train_since_sample = false;   // a train step was queued since the last sampling step: the chains' next launches wait for it (hold_chains)
   // event profiling (bench only)
   bool prof_on = false;
   int prof_cap = 0;
@@ -252,6 +255,7 @@ hipError_t dalloc(Tp** p, size_t n) {
 }
 
 float* pre_buf(sdrm_engine* e, int k) { return e->pre + (size_t)k * e->MPmax * e->WP; }
+float* smp_buf(sdrm_engine* e, int k) { return e->smp_pre + (size_t)k * e->MPmax * e->WP; }   // the sampler's layer buffers
 float* dpre_buf(sdrm_engine* e, int k) { return e->dA + (size_t)k * e->MPmax * e->WP; }   // d loss / d pre-activation k
 const float* slope_ptr(sdrm_engine* e, int layer) { return e->p + (layer == 0 ? e->off_a0 : e->off_ah); }
 
@@ -1041,8 +1045,9 @@ int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, in
   for (int k = 1; k <= e->H; ++k) {
     if (post_act) {
       GemmArgs a{};
-      a.C = pre_buf(e, k) + ro; a.ldc = e->WP; a.bias = nv ? nv->bhc : e->bhc; a.slopeE = nv ? nv->slopeh : slope_ptr(e, k);
-      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, pre_buf(e, k - 1) + ro, e->WP, nv ? nv->Whc : e->Whc, e->WP, MP, e->WP, e->WP,
+      // (nv: a sampling step - the snapshot's weights, the sampler's own layer buffers)
+      a.C = (nv ? smp_buf(e, k) : pre_buf(e, k)) + ro; a.ldc = e->WP; a.bias = nv ? nv->bhc : e->bhc; a.slopeE = nv ? nv->slopeh : slope_ptr(e, k);
+      HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, (nv ? smp_buf(e, k - 1) : pre_buf(e, k - 1)) + ro, e->WP, nv ? nv->Whc : e->Whc, e->WP, MP, e->WP, e->WP,
                                                          st, Prof{e, cls, fl}, cfg)));
       continue;
     }
@@ -1067,6 +1072,16 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
   return SDRM_OK;
 }
 
+// The row chains of a sampling call in progress wait for everything queued on `st` so far (the end of a train step that ran between
+// two of its steps): their launches would otherwise share the chip with the step's one-work-group-per-CU kernels, which then end a
+// whole work-group time later (measured: 8850 -> 8565 steps/s with no dependency at all).
+int hold_chains(sdrm_engine* e, hipStream_t st) {
+  if (!e->chains_pending) return SDRM_OK;
+  HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+  for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
+  return SDRM_OK;
+}
+
 // Row chains for a sampling call of n rows (rows are independent through the whole reverse loop, so a row range can run as a chain
 // of launches on a stream of its own; the ramp and drain of one chain's launch are then filled by the other's).  Measured in round 5
 // (tools/ab/chain_ab.py, profiles/r05_sampler_chains.txt; us per reverse step of the ML-1M net, whole calls): two chains win from
@@ -1075,10 +1090,10 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 // worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
 // (tools/ab/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
 // The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
-// A train step between two sampling steps joins the chains and the next sampling step forks them again (~20 us per train step in
-// bench.py's walk).  Letting them run on beside the train step - the sampler in layer buffers of its own, no join in sdrm_train_forward -
-// was built and measured: 8850 -> 8565 steps/s; a launch of one work-group per CU that finds some CUs busy with the other stream's
-// work-groups ends a whole work-group time later.
+// A train step between two sampling steps (bench.py's walk) does not join the chains: the sampler runs in layer buffers of its own, what
+// the chains have queued may finish beside the start of the step, and their next launches wait for its end (hold_chains).  With no
+// dependency at all - chains running on beside the whole train step - a launch of one work-group per CU finds some CUs busy with the
+// other stream's work-groups and ends a whole work-group time later: 8850 -> 8565 steps/s.
 // While an event profile is recorded (sdrm_profile_begin) the chains run one after the other on the caller's stream: intervals of
 // launches that share the chip would overlap and say nothing about either kernel.
 int chains_for(const Tuning& t, int n, int WP) {
@@ -1418,6 +1433,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, dalloc(&e->Y, MP * e->LP)); HIP_TRY(e, dalloc(&e->dY, MP * e->LP));
   HIP_TRY(e, dalloc(&e->dA, (size_t)(H + 1) * MP * e->WP));   // dpre_buf(0..H)
   HIP_TRY(e, dalloc(&e->X, MP * e->LP)); HIP_TRY(e, dalloc(&e->Us, MP * e->LP));
+  HIP_TRY(e, dalloc(&e->smp_pre, (size_t)(H + 1) * MP * e->WP)); HIP_TRY(e, dalloc(&e->smp_Y, MP * e->LP));
   HIP_TRY(e, dalloc(&e->slab0, (size_t)S_MAX * e->WP * e->K0)); HIP_TRY(e, dalloc(&e->db0s, (size_t)S_MAX * e->WP));
   HIP_TRY(e, dalloc(&e->slabO, (size_t)S_MAX * e->LP * e->WP)); HIP_TRY(e, dalloc(&e->dbOs, (size_t)S_MAX * e->LP));
   if (H >= 1) {
@@ -1452,7 +1468,7 @@ int sdrm_destroy(sdrm_engine* e) {
   (void)hipSetDevice(e->device);
   void* bufs[] = {e->p, e->m, e->v, e->g, e->W0c, e->b0c, e->Whc, e->bhc, e->Woc, e->boc, e->temb, e->tembP, e->B0tab,
                   e->sched, e->U, e->pre, e->Y, e->dY, e->dA, e->X, e->slab0, e->slabH, e->slabO, e->db0s,
-                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->feed_flag, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT};
+                  e->dbHs, e->dbOs, e->alpha_part, e->loss_part, e->sums, e->Mred, e->snap, e->WeP, e->W0eP, e->tdev, e->Tj_dev, e->rowid_dev, e->rev_dev, e->Us, e->WhcT, e->WocT, e->sel, e->one_dev, e->feed_flag, e->smp_w, e->W0f, e->Whf, e->Wof, e->act, e->WhfT, e->WofT, e->smp_pre, e->smp_Y};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (e->xcntF) (void)hipFree(e->xcntF);
@@ -1547,7 +1563,12 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
     return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: EXPLICIT mode needs noise, t and keep");
   if (mode != SDRM_RNG_EXPLICIT && mode != SDRM_RNG_PHILOX) return fail(e, SDRM_ERR_ARG, "bad rng mode");
   hipStream_t st = (hipStream_t)stream;
-  if (int jr = join_chains(e, st)) return jr;
+  // (No join_chains here: a sampling call in progress reads its own snapshot of the net and runs in its own buffers - Us, X, smp_pre,
+  // smp_Y - so what its row chains have queued on the auxiliary streams may finish beside the start of this step; the chains' NEXT
+  // launches wait for the step's end: hold_chains, from the next sdrm_sample_steps - one cross-stream dependency per train step instead of
+  // a join and a fork.)
+  e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
+  e->train_since_sample = true;
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
@@ -2391,11 +2412,11 @@ int launch_sample_persist(sdrm_engine* e, SampleState& s, int count, hipStream_t
     a.A = A; a.lda = lda; a.limA = MP; a.B = Wc; a.ldb = ldw; a.limB = e->WP; a.K = K; a.kchunk = K; a.C = C; a.ldc = ldc;
     return gemm_set_grid(a, tiles_m, tiles_n, 1);
   };
-  bool ok = layer(P.l0, e->Us, e->LP, nv.W0c, e->K0, pre_buf(e, 0), e->WP, e->LP);
+  bool ok = layer(P.l0, e->Us, e->LP, nv.W0c, e->K0, smp_buf(e, 0), e->WP, e->LP);
   P.l0.slopeE = nv.slope0;
-  ok = ok && layer(P.lh, pre_buf(e, 0), e->WP, nv.Whc, e->WP, pre_buf(e, 1), e->WP, e->WP);
+  ok = ok && layer(P.lh, smp_buf(e, 0), e->WP, nv.Whc, e->WP, smp_buf(e, 1), e->WP, e->WP);
   P.lh.bias = nv.bhc; P.lh.slopeE = nv.slopeh;
-  ok = ok && layer(P.lo, pre_buf(e, e->H), e->WP, nv.Woc, e->WP, e->Y, e->LP, e->WP);
+  ok = ok && layer(P.lo, smp_buf(e, e->H), e->WP, nv.Woc, e->WP, e->smp_Y, e->LP, e->WP);
   if (!ok) return fail(e, SDRM_ERR_SHAPE, "persistent sampler: grid beyond the tile arithmetic");
   GemmArgs& a = P.lo;
   a.bias = nv.boc; a.rows_valid = MP; a.cols_valid = e->LP;
@@ -2440,8 +2461,8 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     s.i_next = s.i_next > count ? s.i_next - count : 0;
     return SDRM_OK;
   }
-  // The per-layer path runs in the buffers the train step shares (pre-activations, eps-net outputs): a forward that was
-  // waiting for its backward is gone.
+  // A train forward that was waiting for its backward is dropped (the documented rule of the two-call train API; the sampler has had
+  // layer buffers of its own since round 5 - smp_pre, smp_Y - so whole train steps between sampling steps share nothing with the call).
   e->fwd_done = false;
   e->bwd_begun = false;
   // Train steps may run between sdrm_sample_steps calls (bench.py interleaves them): the sampler reads its own snapshot of
@@ -2451,11 +2472,14 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   const bool serial = e->prof_on;                    // (chains_for: an event profile wants launches that do not share the chip)
   if (serial) {
     if (int jr = join_chains(e, st)) return jr;
+  } else if (e->n_chains > 1 && e->chains_pending && e->train_since_sample) {
+    if (int hr = hold_chains(e, st)) return hr;
   } else if (e->n_chains > 1 && !e->chains_pending) {   // fork: the other chains start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
     for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
     e->chains_pending = true;                        // joined lazily by the next entry point that needs the result
   }
+  e->train_since_sample = false;
   for (int done = 0; done < count && s.i_next >= 1; ++done, --s.i_next) {
     const int i = s.i_next;
     const int na = e->smp_nact[i];                 // active prefix at this step
@@ -2468,7 +2492,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       {
         // the sampler keeps ACTIVATIONS in the layer buffers (EPI_BIAS_PRELU): no backward will ask for the pre-activations
         GemmArgs a{};
-        a.C = pre_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = nv.B0tab + (size_t)i * e->WP; a.slopeE = nv.slope0;
+        a.C = smp_buf(e, 0) + (size_t)s0 * e->WP; a.ldc = e->WP; a.bias = nv.B0tab + (size_t)i * e->WP; a.slopeE = nv.slope0;
         HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_PRELU>(a, e->Us + (size_t)s0 * e->LP, e->LP, nv.W0c, e->K0, MP, e->WP, e->LP, sc,
                                                           Prof{e, PC_SMP_L0, 2.0 * rows * (double)e->W * e->L}, cfg)));
       }
@@ -2481,7 +2505,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
       const bool fused = s.mode == SDRM_RNG_PHILOX && (e->tune.fuse_rev == 2 || (e->tune.fuse_rev == 1 && rows <= FUSE_REV_MAX_ROWS));
       {
         GemmArgs a{};
-        a.C = e->Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = nv.boc;
+        a.C = e->smp_Y + (size_t)s0 * e->LP; a.ldc = e->LP; a.bias = nv.boc;
         a.rows_valid = MP; a.cols_valid = e->LP;
         const Prof pr{e, PC_SMP_OUT, 2.0 * rows * (double)e->L * e->W};
         if (fused) {
@@ -2491,15 +2515,15 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
           a.rev_c1 = c1; a.rev_sqrt_alpha = sqrt_alpha; a.rev_sqrt_beta = sqrt_beta; a.rev_nd = s.nd;
           a.rev_seed_lo = (uint32_t)s.seed; a.rev_seed_hi = (uint32_t)(s.seed >> 32); a.rev_call_id = (uint32_t)s.call_id;
           a.rev_row0 = s.row0; a.rev_rowid = s.multires ? e->rowid_dev : nullptr;
-          HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
+          HIP_TRY(e, (gemm_forward<XF_NONE, EPI_TANH_REV>(a, smp_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
                                                           e->LP, e->WP, sc, pr, cfg)));
           continue;
         }
-        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, pre_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
+        HIP_TRY(e, (gemm_forward<XF_NONE, EPI_BIAS_TANH>(a, smp_buf(e, e->H) + (size_t)s0 * e->WP, e->WP, nv.Woc, e->WP, MP,
                                                          e->LP, e->WP, sc, pr, cfg)));
       }
       ReverseArgs ra{};
-      ra.X = e->X; ra.Y = e->Y; ra.U = e->Us;
+      ra.X = e->X; ra.Y = e->smp_Y; ra.U = e->Us;
       ra.Z = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.z + (size_t)i * nL : nullptr;
       ra.keep_next = (s.mode == SDRM_RNG_EXPLICIT && i > 1) ? s.keep + (size_t)(i - 1) * nL : nullptr;
       ra.Tj = s.multires ? e->Tj_dev : nullptr;
