@@ -50,6 +50,8 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct Tuning {
   int force_cfg = -1;            // SDRM_TILE: -1 = automatic, 0..4 forced tile shape
   int chains = -1;               // SDRM_CHAINS: sampler row chains, -1 = by size, 1..4 forced
+  int hold_early = 1;            // SDRM_HOLD_EARLY: the chains of a sampling call wait for the weight gradients of a train step queued
+                                 // between two of its steps (1) or for the whole step (0): hold_point
   int fuse_rev = 1;              // SDRM_FUSE_REV: reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX
                                  // sampling): 0 never, 1 for launches of at most FUSE_REV_MAX_ROWS rows, 2 always
   int skinny = 1;                // (2: with the 16-user train forward instead of the 4-user one) LDS-resident kernels for nets with padded widths <= 64 (persistent sampler, fused train
@@ -174,8 +176,10 @@ struct sdrm_engine {
   // chain's launch gaps / prologues / tails are filled by another chain's kernels (chain 0 = caller's stream)
   hipStream_t aux[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_hold = nullptr;      // behind the weight gradients of a train step that runs between two sampling steps (hold_point)
   int n_chains = 1, chain_chunk = 0;
   bool chains_pending = false;
+  bool hold_recorded = false;        // ... and its ev_hold was recorded behind that step's weight gradients (hold_point)
   bool train_since_sample = false;   // a train step was queued since the last sampling step: the chains' next launches wait for it (hold_chains)
   // event profiling (bench only)
   bool prof_on = false;
@@ -1077,8 +1081,22 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 // whole work-group time later (measured: 8850 -> 8565 steps/s with no dependency at all).
 int hold_chains(sdrm_engine* e, hipStream_t st) {
   if (!e->chains_pending) return SDRM_OK;
+  if (e->hold_recorded) {   // the train step left its own mark: behind its weight gradients (hold_point)
+    for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_hold, 0));
+    e->hold_recorded = false;
+    return SDRM_OK;
+  }
   HIP_TRY(e, hipEventRecord(e->ev_fork, st));
   for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
+  return SDRM_OK;
+}
+// ... and the point they wait for: behind the step's last MFMA kernel, the weight gradients.  What follows - the tail's two launches -
+// is latency- and HBM-bound on a fraction of the chip; the chains' next GEMMs run beside it (they read the call's snapshot of the net,
+// the tail writes the live parameters).
+int hold_point(sdrm_engine* e, hipStream_t st) {
+  if (!e->chains_pending || !e->tune.hold_early) return SDRM_OK;
+  HIP_TRY(e, hipEventRecord(e->ev_hold, st));
+  e->hold_recorded = true;
   return SDRM_OK;
 }
 
@@ -1326,6 +1344,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   // the only place the environment is read: the settings then belong to this handle
   if (const char* env = std::getenv("SDRM_TILE")) e->tune.force_cfg = std::atoi(env);
   if (const char* env = std::getenv("SDRM_CHAINS")) e->tune.chains = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_HOLD_EARLY")) e->tune.hold_early = std::atoi(env);
   if (const char* env = std::getenv("SDRM_FUSE_REV")) e->tune.fuse_rev = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
@@ -1451,6 +1470,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   HIP_TRY(e, allow_full_lds((const void*)k_tail_emb));
   HIP_TRY(e, dalloc(&e->tdev, max_rows)); HIP_TRY(e, dalloc(&e->Tj_dev, max_rows)); HIP_TRY(e, dalloc(&e->rowid_dev, max_rows));
   HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIP_TRY(e, hipEventCreateWithFlags(&e->ev_hold, hipEventDisableTiming));
   for (int c = 0; c < 3; ++c) {
     HIP_TRY(e, hipStreamCreateWithFlags(&e->aux[c], hipStreamNonBlocking));
     HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join[c], hipEventDisableTiming));
@@ -1481,6 +1501,7 @@ int sdrm_destroy(sdrm_engine* e) {
   for (float* b : e->dec_buf)
     if (b) (void)hipFree(b);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_hold) (void)hipEventDestroy(e->ev_hold);
   for (int c = 0; c < 3; ++c) {
     if (e->ev_join[c]) (void)hipEventDestroy(e->ev_join[c]);
     if (e->aux[c]) (void)hipStreamDestroy(e->aux[c]);
@@ -1568,7 +1589,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   // launches wait for the step's end: hold_chains, from the next sdrm_sample_steps - one cross-stream dependency per train step instead of
   // a join and a fork.)
   e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
-  e->train_since_sample = true;
+  e->train_since_sample = true; e->hold_recorded = false;
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
@@ -1983,6 +2004,7 @@ int sdrm_train_backward_finish(sdrm_engine* e, float* grad, void* stream) {
   float* gout = grad ? grad : e->g;
   if (gout != e->grad_src) return fail(e, SDRM_ERR_ARG, "sdrm_train_backward_finish: different gradient buffer than begin");
   int rc = backward_wgrads(e, st, false);
+  if (!rc) rc = hold_point(e, st);
   if (!rc) rc = backward_tail(e, gout, BUCKET_SECOND, false, 0.f, st);
   e->bwd_begun = false;
   return rc;
@@ -1999,6 +2021,7 @@ static int train_backward_impl(sdrm_engine* e, const double* sums, float* grad, 
   e->grad_src = gout;
   int rc = backward_chain(e, sums, loss, st, false);
   if (!rc) rc = backward_wgrads(e, st, true);
+  if (!rc) rc = hold_point(e, st);
   if (!rc) rc = backward_tail(e, gout, BUCKET_BOTH, fused_lr != nullptr, fused_lr ? *fused_lr : 0.f, st);
   return rc;
 }
