@@ -635,6 +635,9 @@ int emb_tables(sdrm_engine* e, hipStream_t st, const float* warm = nullptr, size
 // updates the parameters and clears `tables_fresh`; the tables are then made by the next consumer - k_emb_tables in front of the
 // row-owned forward, the leading blocks of k_prep_train, the narrow nets' forward itself when T <= 128, or this launch: narrow
 // nets with T > 128 and the sampler pay it as a launch of its own)
+// (Round 5 also made the next row-owned step's tables AHEAD - on aux[2], behind the tail of the last train step, beside the first sampling
+// step that follows it in bench.py's walk: 8967 -> 8907 steps/s in the driver's form, 9069 -> 8994 with the default windows; the fork, the
+// join and a forward that finds its batch cold cost more than the 10 us launch saved.  profiles/r05_walk_transitions.txt)
 int ensure_tables(sdrm_engine* e, hipStream_t st) { return e->tables_fresh ? SDRM_OK : emb_tables(e, st); }
 
 bool skinny_net(const sdrm_engine* e) { return e->tune.skinny && e->LP <= 64 && e->WP <= 64; }
