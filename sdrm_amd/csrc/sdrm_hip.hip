@@ -50,6 +50,7 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct Tuning {
   int force_cfg = -1;            // SDRM_TILE: -1 = automatic, 0..4 forced tile shape
   int chains = -1;               // SDRM_CHAINS: sampler row chains, -1 = by size, 1..4 forced
+  int detach = 1;                // SDRM_DETACH: the one chain of a small sampling call runs on an auxiliary stream (chains_for)
   int hold_early = 1;            // SDRM_HOLD_EARLY: the chains of a sampling call wait for the weight gradients of a train step queued
                                  // between two of its steps (1) or for the whole step (0): hold_point
   int fuse_rev = 1;              // SDRM_FUSE_REV: reverse update fused into the out-layer GEMM epilogue (full-resolution PHILOX
@@ -178,6 +179,9 @@ struct sdrm_engine {
   hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_hold = nullptr;      // behind the weight gradients of a train step that runs between two sampling steps (hold_point)
   int n_chains = 1, chain_chunk = 0;
+  int n_aux = 0;                     // chains on auxiliary streams: n_chains - 1 (the first chain on the caller's stream), or the one chain
+                                     // of a small call, detached (chains_for)
+  bool hold_needed = false;          // the last train forward was a row-owned one (one work-group per CU): chains wait for such a step (hold_chains)
   bool chains_pending = false;
   bool hold_recorded = false;        // ... and its ev_hold was recorded behind that step's weight gradients (hold_point)
   bool train_since_sample = false;   // a train step was queued since the last sampling step: the chains' next launches wait for it (hold_chains)
@@ -1071,7 +1075,7 @@ int hidden_forward(sdrm_engine* e, int MP, int rows, hipStream_t st, int cfg, in
 int join_chains(sdrm_engine* e, hipStream_t st) {
   e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
   if (!e->chains_pending) return SDRM_OK;
-  for (int c = 0; c + 1 < e->n_chains; ++c) {
+  for (int c = 0; c < e->n_aux; ++c) {
     HIP_TRY(e, hipEventRecord(e->ev_join[c], e->aux[c]));
     HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[c], 0));
   }
@@ -1085,19 +1089,19 @@ int join_chains(sdrm_engine* e, hipStream_t st) {
 int hold_chains(sdrm_engine* e, hipStream_t st) {
   if (!e->chains_pending) return SDRM_OK;
   if (e->hold_recorded) {   // the train step left its own mark: behind its weight gradients (hold_point)
-    for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_hold, 0));
+    for (int c = 0; c < e->n_aux; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_hold, 0));
     e->hold_recorded = false;
     return SDRM_OK;
   }
   HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-  for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
+  for (int c = 0; c < e->n_aux; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
   return SDRM_OK;
 }
 // ... and the point they wait for: behind the step's last MFMA kernel, the weight gradients.  What follows - the tail's two launches -
 // is latency- and HBM-bound on a fraction of the chip; the chains' next GEMMs run beside it (they read the call's snapshot of the net,
 // the tail writes the live parameters).
 int hold_point(sdrm_engine* e, hipStream_t st) {
-  if (!e->chains_pending || !e->tune.hold_early) return SDRM_OK;
+  if (!e->chains_pending || !e->tune.hold_early || !e->hold_needed) return SDRM_OK;
   HIP_TRY(e, hipEventRecord(e->ev_hold, st));
   e->hold_recorded = true;
   return SDRM_OK;
@@ -1111,6 +1115,11 @@ int hold_point(sdrm_engine* e, hipStream_t st) {
 // worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
 // (tools/ab/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
 // The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
+// A smaller call is one chain, and that chain runs on an auxiliary stream too (n_aux = 1, "detached"; the caller's stream then carries
+// only what else the job queues): a train step of the per-layer path - eleven dependent launches of 5-13 us on a mostly idle chip -
+// and the four launches of a small sampling step are both latency chains, and two latency chains on two streams fill each other's
+// gaps.  Such a train step does not hold the chains (hold_chains is for row-owned steps, whose one-work-group-per-CU kernels lose a
+// whole work-group time to a busy CU).
 // A train step between two sampling steps (bench.py's walk) does not join the chains: the sampler runs in layer buffers of its own, what
 // the chains have queued may finish beside the start of the step, and their next launches wait for its end (hold_chains).  With no
 // dependency at all - chains running on beside the whole train step - a launch of one work-group per CU finds some CUs busy with the
@@ -1348,6 +1357,7 @@ int sdrm_create(int L, int W, int T, int H, int max_rows, int device_id, sdrm_en
   if (const char* env = std::getenv("SDRM_TILE")) e->tune.force_cfg = std::atoi(env);
   if (const char* env = std::getenv("SDRM_CHAINS")) e->tune.chains = std::atoi(env);
   if (const char* env = std::getenv("SDRM_HOLD_EARLY")) e->tune.hold_early = std::atoi(env);
+  if (const char* env = std::getenv("SDRM_DETACH")) e->tune.detach = std::atoi(env);
   if (const char* env = std::getenv("SDRM_FUSE_REV")) e->tune.fuse_rev = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS")) e->tune.nt32_max_rows = std::atoi(env);
   if (const char* env = std::getenv("SDRM_NT32_MAX_ROWS_TRAIN")) e->tune.nt32_max_rows_train = std::atoi(env);
@@ -1592,6 +1602,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   // launches wait for the step's end: hold_chains, from the next sdrm_sample_steps - one cross-stream dependency per train step instead of
   // a join and a fork.)
   e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
+  if (!e->train_since_sample) e->hold_needed = false;   // (set below by a row-owned forward; kept over several train steps in a row)
   e->train_since_sample = true; e->hold_recorded = false;
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
@@ -1644,6 +1655,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
       HIP_TRY(e, hipGetLastError());
     }
     e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * RC_ROWS; e->cur_x0 = x0; e->cur_grouped = true; e->cur_act = true; e->fwd_done = true;
+    e->hold_needed = true;
     return SDRM_OK;
   }
 
@@ -1660,6 +1672,7 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
       HIP_TRY(e, hipGetLastError());
     }
     e->cur_B = B; e->cur_MP = MPg; e->cur_rows = G * R48_ROWS; e->cur_x0 = x0; e->cur_g16 = true; e->cur_parts = parts; e->cur_act = true;
+    e->hold_needed = true;
     e->fwd_done = true;
     return SDRM_OK;
   }
@@ -2331,6 +2344,7 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   e->n_chains = chains_for(e->tune, n, e->WP);
   e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
+  e->n_aux = e->n_chains > 1 ? e->n_chains - 1 : (e->tune.detach > 0 ? 1 : 0);
   int rc = ensure_tables(e, st);
   if (rc) return rc;
   int i_start = T;
@@ -2498,11 +2512,12 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   const bool serial = e->prof_on;                    // (chains_for: an event profile wants launches that do not share the chip)
   if (serial) {
     if (int jr = join_chains(e, st)) return jr;
-  } else if (e->n_chains > 1 && e->chains_pending && e->train_since_sample) {
-    if (int hr = hold_chains(e, st)) return hr;
-  } else if (e->n_chains > 1 && !e->chains_pending) {   // fork: the other chains start after everything queued on st so far
+  } else if (e->n_aux > 0 && e->chains_pending && e->train_since_sample) {
+    if (e->hold_needed)
+      if (int hr = hold_chains(e, st)) return hr;
+  } else if (e->n_aux > 0 && !e->chains_pending) {   // fork: the chains on auxiliary streams start after everything queued on st so far
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-    for (int c = 0; c + 1 < e->n_chains; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
+    for (int c = 0; c < e->n_aux; ++c) HIP_TRY(e, hipStreamWaitEvent(e->aux[c], e->ev_fork, 0));
     e->chains_pending = true;                        // joined lazily by the next entry point that needs the result
   }
   e->train_since_sample = false;
@@ -2512,7 +2527,7 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
     for (int c = 0; c < e->n_chains; ++c) {
       const int s0 = c * e->chain_chunk, s1 = std::min(na, s0 + e->chain_chunk);
       if (s1 <= s0) break;
-      hipStream_t sc = (c == 0 || serial) ? st : e->aux[c - 1];
+      hipStream_t sc = serial ? st : (e->n_aux == e->n_chains ? e->aux[c] : (c == 0 ? st : e->aux[c - 1]));
       const int rows = s1 - s0, MP = round_up(rows, BM);
       const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows);
       {

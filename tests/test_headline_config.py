@@ -245,3 +245,39 @@ def test_sampler_row_chains_change_no_bit(engine_cls, sample_case, multires):
         pass
     assert bool((e.sample_end().cpu() == outs[-1]).all())
     e.close()
+
+
+@pytest.mark.parametrize("multires", [False, True])
+def test_small_sampling_call_runs_beside_per_layer_train_steps(engine_cls, multires):
+    """A sampling call below the two-chain size (679 rows: one rank of eight) is ONE chain on an auxiliary stream, and train steps of the
+    per-layer path queued between its steps do not hold it (csrc/sdrm_hip.hip: chains_for, hold_chains): the call reads its own snapshot
+    of the net and runs in its own buffers, so the interleaved call - parameters moving under it with every Adam step, its launches
+    sharing the chip with the train steps' - reproduces the uninterrupted one bit for bit, and so do the parameters."""
+    n, B = 679, 512
+    init = synth.init_params(L, W, T, H, seed=31)
+    flat = synth.flatten_params(init, H)
+    x0 = synth.synth_latents(B, L, seed=9)
+    kw = dict(nd=ND, multires=multires, seed=17, call_id=3, row0=1358)
+    e = engine_cls(L, W, T, H, max(n, B))
+    e.set_params(flat)
+    ref = e.sample(n, **kw).cpu()
+    assert e.sampler_chains == 1
+    for k in range(12):
+        e.train_step(x0, 1e-3, seed=3, step=k)
+    p_ref = e.get_params().cpu()
+    e.close()
+    e = engine_cls(L, W, T, H, max(n, B))
+    e.set_params(flat)
+    e.sample_begin(n, **kw)
+    k = 0
+    while e.sample_steps(7) > 0:
+        if k < 12:
+            e.train_step(x0, 1e-3, seed=3, step=k)
+        k += 1
+    out = e.sample_end().cpu()
+    assert k >= 8 and bool((out == ref).all())
+    while k < 12:
+        e.train_step(x0, 1e-3, seed=3, step=k)
+        k += 1
+    assert bool((e.get_params().cpu() == p_ref).all())
+    e.close()
