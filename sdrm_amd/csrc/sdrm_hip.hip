@@ -771,7 +771,11 @@ int rows48_parts(const sdrm_engine* e, int B) {
   // (measured, tools/rows48_probe.py, profiles/r05_rows48_probe.txt: two work-groups per group beat the per-layer path from ~1300
   // users on - B = 2048: 174 against 201 us, B = 1536: 164 against 170 - four per group do not: B = 1024: 140 against 131, the
   // redundant staging and the two hand-shakes per kernel cost what the five launches saved)
-  if (can_split && e->tune.split == 1 && G > 80 && rows48_grid(G, 2) <= 256) return 2;       // 1281 .. 2048 users
+  // ... unless a small sampling call is in progress on its detached chain (chains_for): beside it the eleven launches of the per-layer
+  // path, which it may run along with, beat the column-split kernels, which hold it (tools/ab/walk_host.py, one rank of four - 2048 users,
+  // 1358 sampled rows - in bench.py's walk: 25.2 k -> 27.1 k steps/s).  The two paths differ in the last bits of a step.
+  const bool beside_sampler = e->smp.active && e->chains_pending && e->n_aux == e->n_chains;
+  if (can_split && e->tune.split == 1 && G > 80 && rows48_grid(G, 2) <= 256) return beside_sampler ? 0 : 2;       // 1281 .. 2048 users
   return (G >= 160 && G <= 256) ? 1 : 0;   // (2545 .. 4096 users; measured: 2560 users 231 against 235 us, 2688 231 / 241, 2432 228 / 224)
 }
 
