@@ -72,6 +72,7 @@ class Job:
         self.sampling = False
         self.call_id = 0
         self.handshake_timeouts = 0
+        self.left = 0
 
     def guarded(self, call, retry):
         """The launches that synchronise work-groups through an XCD's L2 (csrc/rows48.h, csrc/sample_persist.h) wait with a bound; a
@@ -91,6 +92,29 @@ class Job:
         ep = (self.train_count // self.wl["batches_per_epoch"]) % self.wl["epochs"]
         return self.wl["lr"] * (1 - ep / self.wl["epochs"])      # train_SDRM.py:316
 
+    def advance(self, budget):
+        """The next train step, or the walk's next run of consecutive sampling steps - at most `budget`, never past the end of the
+        sampling call - in ONE sdrm_sample_steps call (the reference's sampler is one loop over all T steps, train_SDRM.py:50-61; a call
+        per step is host time, and one rank of eight is bound by the host's enqueue rate).  Returns (steps taken, train steps taken)."""
+        wl = self.wl
+        if is_train(self.k, self.n_train, self.cycle):
+            self.step()
+            return 1, 1
+        if not self.sampling:
+            self.e.sample_begin(self.n_local, nd=wl["nd"], seed=self.seed, call_id=self.call_id, row0=self.srow0)
+            self.sampling = True
+            self.call_id += 1
+            self.left = wl["T"]
+        m = 1
+        while m < min(budget, self.left) and not is_train(self.k + m, self.n_train, self.cycle):
+            m += 1
+        self.left = self.e.sample_steps(m)
+        if self.left == 0:
+            self.guarded(self.e.sample_end, retry=False)
+            self.sampling = False
+        self.k += m
+        return m, 0
+
     def step(self):
         wl = self.wl
         if is_train(self.k, self.n_train, self.cycle):
@@ -103,7 +127,9 @@ class Job:
                 self.e.sample_begin(self.n_local, nd=wl["nd"], seed=self.seed, call_id=self.call_id, row0=self.srow0)
                 self.sampling = True
                 self.call_id += 1
-            if self.e.sample_steps(1) == 0:
+                self.left = wl["T"]
+            self.left = self.e.sample_steps(1)
+            if self.left == 0:
                 self.guarded(self.e.sample_end, retry=False)
                 self.sampling = False
             kind = "sample"
@@ -506,13 +532,17 @@ def main():
     # often the walk produces them, over a number of windows that covers whole job cycles - robust like a median,
     # unbiased in the train:sample mix whatever --steps is.
     n_windows = pick_windows(args.steps, n_cycle, args.windows)
-    window_ms, window_trains = [], []
+    window_ms, window_trains, enqueue_ms = [], [], []
     for w in range(n_windows):
         barrier()
         t0 = time.perf_counter()
         n_tr = 0
-        for _ in range(args.steps):
-            n_tr += job.step() == "train"
+        done = 0
+        while done < args.steps:                      # EXACTLY K steps: a run of sampling steps never crosses the window's end
+            m, tr = job.advance(args.steps - done)
+            done += m
+            n_tr += tr
+        enqueue_ms.append((time.perf_counter() - t0) * 1e3)   # the host's share: the loop without the synchronisation behind it
         barrier()
         dt_w = time.perf_counter() - t0
         tmax = torch.tensor([dt_w], dtype=torch.float64, device=dev)
@@ -633,6 +663,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "windows": len(window_ms), "window_ms": [round(v, 3) for v in window_ms], "window_train_steps": window_trains,
             "window_min_ms": round(min(window_ms), 3), "window_max_ms": round(max(window_ms), 3),
+            "host_enqueue_frac": round(sum(enqueue_ms) / sum(window_ms), 3),   # rank 0: time spent queueing the windows' steps / their wall time
             "window_rule": "median per train-step-count class, classes weighted by frequency; windows span whole job cycles",
             "preheat_steps": n_cycle,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

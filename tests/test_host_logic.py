@@ -178,6 +178,47 @@ def test_bench_step_mix():
     assert bench.sample_flops(5429, 340, 78, 1) == pytest.approx(4.12e9, rel=1e-2)
 
 
+def test_bench_walk_in_runs_is_the_walk_in_steps():
+    """bench.py's timed windows take the walk's consecutive sampling steps in one sdrm_sample_steps call (Job.advance): exactly K steps
+    per window whatever K is, the same train / sampling sequence as one step per call, a run never past the end of its sampling call."""
+    import bench
+
+    class Rec:
+        def __init__(self):
+            self.log, self.left = [], 0
+        def sample_begin(self, n, **kw):
+            self.log.append(("begin",)); self.left = 78
+        def sample_steps(self, k):
+            assert 1 <= k <= self.left
+            self.log.append(("steps", k)); self.left -= k
+            return self.left
+        def sample_end(self):
+            assert self.left == 0
+            self.log.append(("end",))
+    class Tr:
+        def __init__(self, rec): self.rec = rec
+        def train_step(self, *a, **kw): self.rec.log.append(("train",))
+    wl = {"epochs": 3, "batches_per_epoch": 5, "T": 78, "nd": 1.0, "lr": 1e-3}
+    def flat(log):
+        out = []
+        for ev in log:
+            out += [("steps", 1)] * ev[1] if ev[0] == "steps" else [ev]
+        return out
+    for K in (1, 7, 20, 93, 186, 250):
+        r1, r2 = Rec(), Rec()
+        j1, j2 = bench.Job(r1, Tr(r1), None, 0, 10, 0, wl), bench.Job(r2, Tr(r2), None, 0, 10, 0, wl)
+        for w in range(11):
+            done = trains = 0
+            while done < K:
+                m, tr = j1.advance(K - done)
+                assert m >= 1 and done + m <= K
+                done += m; trains += tr
+            kinds = [j2.step() for _ in range(K)]
+            assert trains == kinds.count("train") and j1.k == j2.k and j1.train_count == j2.train_count
+        assert flat(r1.log) == flat(r2.log)
+        assert len(r1.log) < len(r2.log) or K == 1
+
+
 def test_bench_window_rule():
     """bench.py times several K-step windows along the cyclic walk: their number covers whole job cycles and the
     combination is unbiased in the train:sample mix even when one window cannot hold the mix (K = 20: 3 or 4 train steps)."""
