@@ -192,7 +192,11 @@ int sdrm_sample(sdrm_engine* e, int n, float noise_divider, int multires, int mo
  * that sdrm_sample_begin itself issues): sdrm_set_params or train steps issued after the begin, between its sdrm_sample_steps
  * calls, do not change its result.  The streams of the begin / steps / end calls of one sampling call must be the same or
  * ordered by the caller.  The EXPLICIT-mode pointers must stay valid until sdrm_sample_end.  sdrm_sample_steps runs at most `count` reverse
- * steps; sdrm_sample_remaining returns the next step index i (0 = loop finished). */
+ * steps; sdrm_sample_remaining returns the next step index i (0 = loop finished).
+ * The steps are queued, not necessarily on `stream`: the engine runs row ranges of a call as chains of launches on streams of its own
+ * (ordered after everything queued on `stream` at the first sdrm_sample_steps; folded back into `stream` by sdrm_sample_end and by every
+ * other entry point that touches the sampler's state), so a train step queued between two sdrm_sample_steps calls may execute beside
+ * the call's launches.  Neither sees the other: the call's result and the train steps' are those of the sequential order, bit for bit. */
 int sdrm_sample_begin(sdrm_engine* e, int n, float noise_divider, int multires, int mode, const float* xT,
                       const float* z, const uint8_t* keep, const int64_t* Tj, uint64_t seed, uint64_t call_id,
                       int64_t row0, int64_t* Tj_out, void* stream);

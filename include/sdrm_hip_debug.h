@@ -103,7 +103,11 @@ int sdrm_debug_set_fused_reverse(sdrm_engine* e, int mode);
  * update go by a chain's row count, so the last bits may differ between chain counts (never between two runs of one). */
 int sdrm_debug_set_chains(sdrm_engine* e, int chains);
 /* The number of row chains of the sampling call in progress (or of the last one); by size: two once the call has 2560 x 352 elements
- * per layer (ML-1M: n >= 2560 rows).  While an event profile is recorded (sdrm_profile_begin) the chains run one after the other. */
+ * per layer (ML-1M: n >= 2560 rows).  While an event profile is recorded (sdrm_profile_begin) the chains run one after the other.
+ * How chains and train steps queued between sampling steps share the chip (csrc/sdrm_hip.hip: chains_for, hold_chains, hold_point) has two
+ * environment switches for A/B runs, read at sdrm_create: SDRM_DETACH=0 keeps the one chain of a small call on the caller's stream
+ * (default: on an auxiliary stream, beside train steps of the per-layer path), SDRM_HOLD_EARLY=0 makes the chains wait for the end of a
+ * row-owned train step (default: for its weight gradients; the tail runs beside them). */
 int sdrm_debug_chains(const sdrm_engine* e);
 
 /* Gradient all-reduces of sdrm_train_step_sharded: 1 (default) = one all-reduce of the whole flat gradient after the one-call
