@@ -181,6 +181,8 @@ struct sdrm_engine {
   int n_chains = 1, chain_chunk = 0;
   int n_aux = 0;                     // chains on auxiliary streams: n_chains - 1 (the first chain on the caller's stream), or the one chain
                                      // of a small call, detached (chains_for)
+  bool detach_armed = false;         // a train step was queued beside a small call on the caller's stream: ev_fork marks the point behind the
+                                     // call's last step, the next sdrm_sample_steps moves the chain to aux[0] (sdrm_train_forward)
   bool hold_needed = false;          // the last train forward was a row-owned one (one work-group per CU): chains wait for such a step (hold_chains)
   bool chains_pending = false;
   bool hold_recorded = false;        // ... and its ev_hold was recorded behind that step's weight gradients (hold_point)
@@ -774,7 +776,7 @@ int rows48_parts(const sdrm_engine* e, int B) {
   // ... unless a small sampling call is in progress on its detached chain (chains_for): beside it the eleven launches of the per-layer
   // path, which it may run along with, beat the column-split kernels, which hold it (tools/ab/walk_host.py, one rank of four - 2048 users,
   // 1358 sampled rows - in bench.py's walk: 25.2 k -> 27.1 k steps/s).  The two paths differ in the last bits of a step.
-  const bool beside_sampler = e->smp.active && e->chains_pending && e->n_aux == e->n_chains;
+  const bool beside_sampler = e->smp.active && (e->detach_armed || (e->chains_pending && e->n_aux == e->n_chains));
   if (can_split && e->tune.split == 1 && G > 80 && rows48_grid(G, 2) <= 256) return beside_sampler ? 0 : 2;       // 1281 .. 2048 users
   return (G >= 160 && G <= 256) ? 1 : 0;   // (2545 .. 4096 users; measured: 2560 users 231 against 235 us, 2688 231 / 241, 2432 228 / 224)
 }
@@ -1119,8 +1121,8 @@ int hold_point(sdrm_engine* e, hipStream_t st) {
 // worse inside a job that trains between sampling steps; more than two are not what the host's launch rate bounds
 // (tools/ab/chain_threads.py: one host thread per chain gives the same 43.4; a captured graph with forked streams replays at 65).
 // The rule: two chains once the call has 2560 x 352 elements per layer, i.e. each chain's launch still has ~130 work-groups.
-// A smaller call is one chain, and that chain runs on an auxiliary stream too (n_aux = 1, "detached"; the caller's stream then carries
-// only what else the job queues): a train step of the per-layer path - eleven dependent launches of 5-13 us on a mostly idle chip -
+// A smaller call is one chain on the caller's stream - until a train step is queued beside it: from then on the chain runs on an
+// auxiliary stream (n_aux = 1, "detached", sdrm_train_forward; the caller's stream then carries the train steps): a train step of the per-layer path - eleven dependent launches of 5-13 us on a mostly idle chip -
 // and the four launches of a small sampling step are both latency chains, and two latency chains on two streams fill each other's
 // gaps.  Such a train step does not hold the chains (hold_chains is for row-owned steps, whose one-work-group-per-CU kernels lose a
 // whole work-group time to a busy CU).
@@ -1593,6 +1595,9 @@ int sdrm_adam_reset(sdrm_engine* e, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+namespace {
+bool sample_persist_fits(const sdrm_engine* e, const SampleState& s);   // (below, beside the sampler)
+}
 int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int mode, const sdrm_train_randoms* rnd,
                        uint64_t seed, uint64_t step, float nd, double* sums, void* stream) {
   if (!e || !x0) return fail(e, SDRM_ERR_ARG, "sdrm_train_forward: null pointer");
@@ -1608,6 +1613,14 @@ int sdrm_train_forward(sdrm_engine* e, const float* x0, int B, int64_t row0, int
   e->bwd_begun = false;   // a backward that was begun but never finished is abandoned
   if (!e->train_since_sample) e->hold_needed = false;   // (set below by a row-owned forward; kept over several train steps in a row)
   e->train_since_sample = true; e->hold_recorded = false;
+  // A small sampling call (one chain) runs on the caller's stream until a train step is queued beside it - on a stream of its own a
+  // plain call is ~3 us per step SLOWER (tools/ab/detach_ab.py: 679 rows 17.0 -> 19.7, ML-100k 58.1 -> 62.4).  From here on its chain
+  // is detached (chains_for): the mark behind its last step is taken now, in front of this step's launches.
+  if (e->tune.detach > 0 && e->smp.active && !e->smp.skinny && e->smp.i_next >= 1 && e->n_chains == 1 && e->n_aux == 0 && !e->detach_armed &&
+      !e->prof_on && !sample_persist_fits(e, e->smp)) {
+    HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+    e->detach_armed = true;
+  }
   const int MP = round_up(3 * B, BM), n = e->T + 1;
   const int cfg = choose_cfg(e->tune, MP, e->tune.nt32_max_rows_train);   // one tile for every NT launch of the step
   e->fwd_done = false;
@@ -2348,7 +2361,8 @@ int sdrm_sample_begin(sdrm_engine* e, int n, float nd, int multires, int mode, c
   e->n_chains = chains_for(e->tune, n, e->WP);
   e->chain_chunk = round_up((n + e->n_chains - 1) / e->n_chains, BM);
   e->n_chains = (n + e->chain_chunk - 1) / e->chain_chunk;
-  e->n_aux = e->n_chains > 1 ? e->n_chains - 1 : (e->tune.detach > 0 ? 1 : 0);
+  e->n_aux = e->n_chains > 1 ? e->n_chains - 1 : 0;   // (the one chain of a small call: detached by the first train step queued beside it)
+  e->detach_armed = false;
   int rc = ensure_tables(e, st);
   if (rc) return rc;
   int i_start = T;
@@ -2515,7 +2529,15 @@ int sdrm_sample_steps(sdrm_engine* e, int count, void* stream) {
   const NetView nv = snapshot_view(e);
   const bool serial = e->prof_on;                    // (chains_for: an event profile wants launches that do not share the chip)
   if (serial) {
+    e->detach_armed = false;
     if (int jr = join_chains(e, st)) return jr;
+  } else if (e->detach_armed) {                         // the first steps behind a train step that was queued beside this small call
+    e->n_aux = 1;
+    HIP_TRY(e, hipStreamWaitEvent(e->aux[0], e->ev_fork, 0));
+    e->chains_pending = true;
+    e->detach_armed = false;
+    if (e->hold_needed)                                 // (a row-owned step: not beside its MFMA kernels)
+      if (int hr = hold_chains(e, st)) return hr;
   } else if (e->n_aux > 0 && e->chains_pending && e->train_since_sample) {
     if (e->hold_needed)
       if (int hr = hold_chains(e, st)) return hr;

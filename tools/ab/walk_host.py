@@ -24,5 +24,6 @@ def walk(cycles):
         k += 1
 walk(2); torch.cuda.synchronize()
 for rep in range(3):
+    l0 = e.launch_count()
     t0 = time.perf_counter(); walk(4); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"B={B} n={n} chains={e.sampler_chains}: enqueue {1e3 * (t1 - t0) / 4:.3f} ms per cycle, with sync {1e3 * (t2 - t0) / 4:.3f} ms per cycle -> {93 * 4 / (t2 - t0):.0f} steps/s", flush=True)
+    print(f"B={B} n={n} chains={e.sampler_chains} launches per cycle {(e.launch_count() - l0) / 4:.0f}: enqueue {1e3 * (t1 - t0) / 4:.3f} ms per cycle, with sync {1e3 * (t2 - t0) / 4:.3f} ms per cycle -> {93 * 4 / (t2 - t0):.0f} steps/s", flush=True)
