@@ -125,6 +125,12 @@ def load(build_if_missing: bool = True):
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm ships its own libamdhip64: it must be the HIP runtime this process loads FIRST.  Loaded after a system copy that the
+    # library's DT_NEEDED pulled in, it finds no device ("no ROCm-capable device is detected" from sdrm_create on a box with a GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - a C-ABI-only consumer without PyTorch: the system runtime is then the only one
+        pass
     path = lib_path()
     override = os.environ.get("SDRM_LIB")   # diagnostics only (tools/ab_bench.sh): another build of the same ABI, loaded as it is
     if override:
