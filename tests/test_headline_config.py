@@ -281,3 +281,63 @@ def test_small_sampling_call_runs_beside_per_layer_train_steps(engine_cls, multi
         k += 1
     assert bool((e.get_params().cpu() == p_ref).all())
     e.close()
+
+
+def test_train_steps_beside_a_small_call_at_the_column_split_size(engine_cls):
+    """2048 users, 1358 sampled rows (one rank of four): a train step queued beside the detached chain takes the per-layer path instead of
+    the column-split kernels (csrc/sdrm_hip.hip: rows48_parts).  The sampling call is the plain call bit for bit; the first such step's
+    loss and gradient are those of the sequential run's first step - on the column-split path - within the rounding of the two paths
+    (later steps are only exercised: Adam's first updates are lr * sign(g), which turns a last-bit difference of a near-zero gradient
+    into 2 lr)."""
+    n, B = 1358, 2048
+    flat = synth.flatten_params(synth.init_params(L, W, T, H, seed=33), H)
+    x0 = synth.synth_latents(B, L, seed=10)
+    kw = dict(nd=ND, seed=19, call_id=4, row0=2716)
+    e = engine_cls(L, W, T, H, B)
+    e.set_params(flat)
+    ref = e.sample(n, **kw).cpu()
+    loss_ref = float(e.train_step(x0, 1e-3, seed=3, step=0).cpu())
+    g_ref = e.get_grads().cpu().numpy()
+    e.close()
+    e = engine_cls(L, W, T, H, B)
+    e.set_params(flat)
+    e.sample_begin(n, **kw)
+    k = 0
+    while e.sample_steps(11) > 0:
+        if k < 6:
+            loss = float(e.train_step(x0, 1e-3, seed=3, step=k).cpu())
+            if k == 0:
+                g = e.get_grads().cpu().numpy()
+                assert abs(loss - loss_ref) <= 2e-5 * abs(loss_ref)
+                for (name, a), (_, b) in zip(per_tensor(g, (L, W, T, H)), per_tensor(g_ref, (L, W, T, H))):
+                    assert rel_l2(a, b) <= TOL and rel_max(a, b) <= 10 * TOL, (name, rel_l2(a, b), rel_max(a, b))
+        k += 1
+    out = e.sample_end().cpu()
+    assert k >= 6 and bool((out == ref).all())
+    e.close()
+
+
+def test_abandoned_and_closed_sampling_calls_with_chains_in_flight(engine_cls, sample_case):
+    """A sampling call that is dropped while its chains are in flight - a new sdrm_sample_begin, or the engine closed - leaves nothing behind:
+    the next call is the plain call, bit for bit."""
+    c = sample_case["philox"]
+    flat = synth.flatten_params(sample_case["init"], H)
+    x0 = synth.synth_latents(1024, L, seed=8)
+    for n in (679, N_SAMPLE):     # one detached chain / two chains
+        kw = dict(nd=ND, seed=c["seed"], call_id=c["call_id"], row0=c["row0"])
+        e = engine_cls(L, W, T, H, max(n, 1024))
+        e.set_params(flat)
+        ref = e.sample(n, **kw).cpu()
+        e.sample_begin(n, **kw)
+        e.sample_steps(10)
+        e.train_step(x0, 0.0, seed=3, step=0)      # lr = 0: the net stays what it is; the chain is detached / held
+        e.sample_steps(5)
+        e.sample_begin(n, **kw)                     # abandons the call above
+        while e.sample_steps(13) > 0:
+            pass
+        assert bool((e.sample_end().cpu() == ref).all())
+        e.sample_begin(n, **kw)
+        e.sample_steps(20)
+        e.train_step(x0, 0.0, seed=3, step=1)
+        e.sample_steps(3)
+        e.close()                                   # chains in flight
