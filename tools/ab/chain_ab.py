@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 L, W, T, H = 340, 340, 78, 1

@@ -2,7 +2,7 @@
 whole calls from stream launches (GPU time by events, and the host's enqueue time alone), and the same call replayed from a captured
 graph (chains fork and join inside the capture)."""
 import os, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 L, W, T, H = 340, 340, 78, 1

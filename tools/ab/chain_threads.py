@@ -2,7 +2,7 @@
 stream of its own, driven by k host threads (the ctypes call releases the GIL; a call is 78 steps): wall-clock us per reverse step of the
 n rows together."""
 import os, sys, time, threading, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 L, W, T, H = 340, 340, 78, 1

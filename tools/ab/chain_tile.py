@@ -1,6 +1,6 @@
 """Two sampler row chains: which tile and which form of the reverse update per chain?  us per reverse step, whole calls."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 L, W, T, H = 340, 340, 78, 1

@@ -1,7 +1,7 @@
 """The one chain of a small sampling call on an auxiliary stream (SDRM_DETACH=1, default) against the caller's stream (=0): us per reverse
 step of whole calls and of one step per call, no train steps in between."""
 import os, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 cases = [("ML-1M n=679", 340, 340, 78, 1, 679), ("ML-1M n=1358", 340, 340, 78, 1, 1358), ("ML-100k n=843", 830, 830, 83, 2, 843)]

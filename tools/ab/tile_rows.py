@@ -1,5 +1,5 @@
 import ctypes as C, os, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import _lib
 lib = _lib.load()
 def run(M, cfg, reps=200):

@@ -1,7 +1,7 @@
 """Is bench.py's walk bound by the host at shard sizes?  One rank of eight (1024 users, 679 sampled rows): wall time of the enqueue loop
 alone against the loop + device sync, per job cycle, with the sampling call on the caller's stream (SDRM_DETACH=0) or detached (=1)."""
 import os, sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sdrm_amd import synth
 from sdrm_amd.engine import Engine
 L, W, T, H = 340, 340, 78, 1
